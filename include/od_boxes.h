@@ -1,0 +1,163 @@
+/*
+ * od_boxes.h -- C ABI of libod_boxes.so: the detection-head box pipeline on MI355X (gfx950).
+ *
+ * The reference (Kotaro-Kuroda/object_detection v0.3.5) has no FFI: it is pure Python and reaches
+ * this arithmetic through torchvision 0.16.2 objects it constructs in
+ * object_detection/retinanet/retinanet_model.py:19-61 and calls in object_detection/train.py:62,84 and
+ * object_detection/predict.py:61,72.  Each entry point below names the torchvision function(s) it
+ * replaces and the reference line that puts them on the path.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter comment says "host";
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *   - no entry point allocates or frees device memory; scratch comes in through `workspace`
+ *     (size from the matching *_workspace_bytes function, 256-byte aligned);
+ *   - return value: 0 = ok; < 0 = OD_ERR_* (bad argument / documented limit / workspace too small);
+ *     > 0 = a hipError_t from the runtime.  Nothing throws or exits;
+ *   - boxes are fp32 xyxy, AoS [.,4]; indices/labels returned to callers are int64 like torchvision's;
+ *   - preconditions for bit-exact matching: finite coordinates, x2 >= x1 and y2 >= y1 for GT boxes,
+ *     anchors with positive area (what torchvision's forward asserts for targets).
+ */
+#ifndef OD_BOXES_H
+#define OD_BOXES_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OD_MAX_LEVELS 8
+#define OD_MAX_BASE_ANCHORS 16
+#define OD_MAX_TOPK 4096        /* topk_candidates limit of od_select_candidates */
+#define OD_MAX_NMS_BOXES 8192   /* boxes per image limit of od_batched_nms */
+
+#define OD_CODER_BOXCODER 0     /* BoxCoder(weights=(1,1,1,1)).decode_single  (RetinaNet) */
+#define OD_CODER_LINEAR 1       /* BoxLinearCoder(normalize_by_size=True).decode (FCOS)   */
+
+#define OD_NMS_TRICK 0          /* _batched_nms_coordinate_trick */
+#define OD_NMS_VANILLA 1        /* _batched_nms_vanilla          */
+#define OD_NMS_AUTO_CPU 2       /* batched_nms rule for device.type == "cpu": numel > 4000 -> vanilla */
+#define OD_NMS_AUTO_GPU 3       /* batched_nms rule otherwise:               numel > 20000 -> vanilla */
+
+/* Library version (major*10000 + minor*100 + patch). */
+int od_version(void);
+
+/*
+ * Anchor generation.  Replaces torchvision.models.detection.anchor_utils.AnchorGenerator.grid_anchors
+ * / forward (built at reference retinanet_model.py:22-27,42-46; called inside model(...) at
+ * train.py:62,84, predict.py:61).  Output order (level, y, x, a); anchors = int32 shift + base.
+ *   grid_h, grid_w, stride_h, stride_w, num_base : host int32[num_levels]
+ *   base_anchors : host fp32 [sum(num_base), 4] -- the rounded cell anchors of every level
+ *   out          : fp32 [n_total, 4], 16-byte aligned;  n_total = sum(grid_h*grid_w*num_base)
+ */
+int od_anchor_generate(const int32_t* grid_h, const int32_t* grid_w, const int32_t* stride_h,
+                       const int32_t* stride_w, const int32_t* num_base, const float* base_anchors,
+                       int32_t num_levels, float* out, int64_t n_total, void* stream);
+
+/*
+ * Fused box_iou + Matcher.  Replaces, per image, torchvision.ops.boxes.box_iou(gt, anchors) followed
+ * by torchvision.models.detection._utils.Matcher(high, low, allow_low_quality_matches)(iou) -- the
+ * loop body of RetinaNet.compute_loss (reference trigger train.py:62 with the thresholds of
+ * configs/config_all.py:10-11 forwarded at train.py:144).  The [M,N] matrix is never materialised.
+ *   anchors             : fp32 [n,4] (anchor_batch_stride = 0, shared by all images) or
+ *                         [batch, n, 4] (anchor_batch_stride = n), 16-byte aligned
+ *   gt_boxes            : fp32 [gt_offsets[batch], 4], images concatenated, 16-byte aligned
+ *   gt_offsets          : int32 [batch+1], CSR offsets into gt_boxes (device)
+ *   m_total             : gt_offsets[batch] as known to the host (sizes the workspace)
+ *   matched             : int64 [batch, n]: matched GT index, -1 below `low`, -2 between thresholds;
+ *                         an image with zero GT boxes gets all -1 (compute_loss's empty-target guard)
+ */
+size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch);
+int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n, const float* gt_boxes,
+                       const int32_t* gt_offsets, int64_t m_total, int32_t batch, float high, float low,
+                       int32_t allow_low_quality, int64_t* matched, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/*
+ * FCOS centre-sampling matcher.  Replaces the matching loop of torchvision FCOS.compute_loss
+ * (reference trigger retinanet_model.py:55-60 + train.py:62).  n_first_level / n_last_level are
+ * num_anchors_per_level[0] / [-1] (lower bound 0 on the first level, upper bound inf on the last).
+ * Same anchors / gt layout as od_match_retinanet.  matched: int64 [batch, n], -1 = unmatched.
+ */
+int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, int64_t n, int64_t n_first_level,
+                  int64_t n_last_level, const float* gt_boxes, const int32_t* gt_offsets, int32_t batch,
+                  float center_sampling_radius, int64_t* matched, void* stream);
+
+/*
+ * Pairwise IoU matrix.  Replaces torchvision.ops.boxes.box_iou (public op; used by callers that want
+ * the matrix itself).  out: fp32 [m, n] row-major, row = boxes1 index.
+ */
+int od_box_iou(const float* boxes1, int64_t m, const float* boxes2, int64_t n, float* out, void* stream);
+
+/*
+ * Matcher on an explicit quality matrix.  Replaces torchvision Matcher.__call__ /
+ * set_low_quality_matches_ for callers that hold a matrix (model.proposal_matcher(matrix)).
+ *   quality : fp32 [m, n] row-major (m = GT, n = predictions), m >= 1, n >= 1
+ *   workspace : od_matcher_workspace_bytes(m, n)
+ */
+size_t od_matcher_workspace_bytes(int64_t m, int64_t n);
+int od_matcher(const float* quality, int64_t m, int64_t n, float high, float low, int32_t allow_low_quality,
+               int64_t* matches, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Box decoding + clipping.  Replaces BoxCoder.decode_single / BoxLinearCoder.decode followed
+ * (when clip_h > 0) by torchvision.ops.boxes.clip_boxes_to_image.  exp() is the library's specified
+ * fp32 algorithm; rel_codes, boxes, out: fp32 [n,4].
+ */
+int od_decode_boxes(const float* rel_codes, const float* boxes, int64_t n, int32_t coder,
+                    float bbox_xform_clip, float clip_h, float clip_w, float* out, void* stream);
+
+/*
+ * Score filter + top-k + decode + clip for every (image, level).  Replaces the inner loop of
+ * RetinaNet.postprocess_detections / FCOS.postprocess_detections up to and including
+ * clip_boxes_to_image (reference trigger train.py:84, predict.py:61; knobs predict.py:44-45).
+ *   cls_logits[l]      : host array of device pointers, level l tensor [batch, level_size[l], num_classes]
+ *   cls_batch_stride[l]: host int64, elements between consecutive images of level l
+ *   bbox_ctrness       : NULL (RetinaNet: score = sigmoid(cls)) or like cls_logits with 1 value per
+ *                        anchor (FCOS: score = sqrt(sigmoid(cls) * sigmoid(ctrness)))
+ *   bbox_regression[l] : [batch, level_size[l], 4];  anchors[l]: [level_size[l], 4] (stride 0) or batched
+ *   image_hw           : int32 [batch, 2] (height, width) device -- clip limits
+ *   outputs, padded per (image, level) to `topk` slots, slot = level*topk + rank:
+ *     cand_boxes fp32 [batch, L*topk, 4]; cand_scores fp32 [batch, L*topk]; cand_labels int32;
+ *     cand_index int64 (flat index anchor*num_classes + class inside the level; may be NULL);
+ *     cand_count int32 [batch, L].  Candidates of a level are ordered by (score desc, flat index asc).
+ */
+size_t od_select_candidates_workspace_bytes(const int64_t* level_size, int32_t num_levels, int32_t batch,
+                                            int32_t num_classes);
+int od_select_candidates(const float* const* cls_logits, const int64_t* cls_batch_stride,
+                         const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
+                         const float* const* bbox_regression, const int64_t* reg_batch_stride,
+                         const float* const* anchors, const int64_t* anchor_batch_stride,
+                         const int64_t* level_size, int32_t num_levels, int32_t batch, int32_t num_classes,
+                         const int32_t* image_hw, float score_thresh, int32_t topk, int32_t coder,
+                         float bbox_xform_clip, float* cand_boxes, float* cand_scores, int32_t* cand_labels,
+                         int64_t* cand_index, int32_t* cand_count, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/*
+ * Class-batched NMS for a batch of images.  Replaces torchvision.ops.boxes.batched_nms
+ * (_batched_nms_coordinate_trick / _batched_nms_vanilla) + the native torchvision::nms op +
+ * `keep[:max_keep]` + the gather of boxes/scores/labels (tail of postprocess_detections).
+ * Greedy order = stable descending score (ties: lower index first); box j is suppressed by a kept
+ * box i when fp32 inter/(area_i+area_j-inter), promoted to double, is > iou_threshold.
+ *   boxes [batch, num_seg*seg_stride, 4], scores, labels (int32, NULL = one class): padded segments;
+ *   seg_count int32 [batch, num_seg]: valid entries at the head of each segment (device).
+ *   segments_sorted: nonzero if every segment is already in (score desc, index asc) order.
+ *   Indices written to keep_idx count valid entries only (the index a torch.cat of the segments
+ *   would give).  Outputs: keep_idx int64 [batch, max_keep] (may be NULL), out_boxes fp32
+ *   [batch, max_keep, 4], out_scores fp32, out_labels int64 (NULL allowed), out_count int32 [batch].
+ *   Rows past out_count are zero-filled.  Limit: num_seg*seg_stride <= OD_MAX_NMS_BOXES.
+ */
+size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride);
+int od_batched_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* seg_count,
+                   int32_t num_seg, int32_t seg_stride, int32_t segments_sorted, int32_t batch,
+                   double iou_threshold, int32_t mode, int32_t max_keep, int64_t* keep_idx, float* out_boxes,
+                   float* out_scores, int64_t* out_labels, int32_t* out_count, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OD_BOXES_H */

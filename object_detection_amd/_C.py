@@ -1,0 +1,79 @@
+"""ctypes binding of ``libod_boxes.so`` (the C ABI declared in ``include/od_boxes.h``).
+
+The library is the product: there is no CPU or eager fallback.  If the shared object is missing
+or a symbol cannot be resolved, importing a kernel raises immediately with the build command.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libod_boxes.so")
+
+OD_MAX_LEVELS = 8
+OD_MAX_BASE_ANCHORS = 16
+OD_MAX_TOPK = 4096
+OD_MAX_NMS_BOXES = 8192
+CODER_BOXCODER, CODER_LINEAR = 0, 1
+NMS_TRICK, NMS_VANILLA, NMS_AUTO_CPU, NMS_AUTO_GPU = 0, 1, 2, 3
+
+_ERRORS = {
+    -1: "invalid argument (null pointer, negative size, misaligned or inconsistent shapes)",
+    -2: "size beyond a documented limit of libod_boxes",
+    -3: "workspace too small",
+}
+
+_P = c_void_p
+# name -> (restype, argtypes); must list every symbol of include/od_boxes.h
+SIGNATURES = {
+    "od_version": (c_int32, []),
+    "od_anchor_generate": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, _P]),
+    "od_match_retinanet_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "od_match_retinanet": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_float, c_float, c_int32,
+                                     _P, _P, c_size_t, _P]),
+    "od_match_fcos": (c_int32, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int32, c_float, _P, _P]),
+    "od_box_iou": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),
+    "od_matcher_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "od_matcher": (c_int32, [_P, c_int64, c_int64, c_float, c_float, c_int32, _P, _P, c_size_t, _P]),
+    "od_decode_boxes": (c_int32, [_P, _P, c_int64, c_int32, c_float, c_float, c_float, _P, _P]),
+    "od_select_candidates_workspace_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
+    "od_select_candidates": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_float,
+                                       c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
+                                 _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+class OdBoxesError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Load libod_boxes.so once; raise loudly if it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: the HIP kernels are not built. Run "
+                f"`make -C {os.path.join(_HERE, 'csrc')}` (needs hipcc, targets gfx950) or "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` from the repository root.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int, what: str) -> None:
+    if code == 0:
+        return
+    if code < 0:
+        raise OdBoxesError(f"{what}: {_ERRORS.get(code, 'error')} (code {code})")
+    raise OdBoxesError(f"{what}: HIP runtime error {code}")

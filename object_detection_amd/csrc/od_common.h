@@ -1,0 +1,141 @@
+// Shared device helpers for the box-pipeline kernels (gfx950 / CDNA4, wave64).
+// Build flags that the numerics below rely on: -ffp-contract=off (no FMA fusion), default
+// correctly rounded fp32 division and sqrt, fp32 denormals preserved (hipcc defaults).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define OD_OK 0
+#define OD_ERR_ARG (-1)        // null pointer / negative size / inconsistent shapes
+#define OD_ERR_LIMIT (-2)      // size beyond a documented limit of this library
+#define OD_ERR_WORKSPACE (-3)  // workspace too small
+
+#define OD_LAUNCH_CHECK()                         \
+    do {                                          \
+        hipError_t e__ = hipGetLastError();       \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+#define OD_HIP(call)                              \
+    do {                                          \
+        hipError_t e__ = (call);                  \
+        if (e__ != hipSuccess) return (int)e__;   \
+    } while (0)
+
+namespace od {
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// Order-preserving map float -> uint32 (total order, -0 < +0, NaN(+) above +inf).
+__device__ __forceinline__ uint32_t ordered_key(float f) {
+    uint32_t b = f2u(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_key_inv(uint32_t k) {
+    return u2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// ---- wave64 reductions over DPP (no LDS traffic). Result valid in lane 63. --------------------
+// old = 0 with bound_ctrl off: lanes without a source keep 0, the identity of umax / add / or.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+__device__ __forceinline__ uint32_t wave_umax_lane63(uint32_t v) {
+    v = max(v, dpp_u32<0x111>(v));        // row_shr:1
+    v = max(v, dpp_u32<0x112>(v));        // row_shr:2
+    v = max(v, dpp_u32<0x114>(v));        // row_shr:4
+    v = max(v, dpp_u32<0x118>(v));        // row_shr:8  -> lane 15 of each row holds the row max
+    v = max(v, dpp_u32<0x142, 0xa>(v));   // row_bcast:15 into rows 1 and 3
+    v = max(v, dpp_u32<0x143, 0xc>(v));   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ uint32_t wave_umax_all(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_umax_lane63(v), 63);
+}
+
+__device__ __forceinline__ float wave_fmax_all(float v) {   // any floats (uses the ordered key)
+    return ordered_key_inv(wave_umax_all(ordered_key(v)));
+}
+__device__ __forceinline__ float wave_fmin_all(float v) {
+    return ordered_key_inv(~wave_umax_all(~ordered_key(v)));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_all(uint32_t v) {
+    v += dpp_u32<0x111>(v);
+    v += dpp_u32<0x112>(v);
+    v += dpp_u32<0x114, 0xf, 0xe>(v);     // rocPRIM-style masks keep the partial sums disjoint
+    v += dpp_u32<0x118, 0xf, 0xc>(v);
+    v += dpp_u32<0x142, 0xa>(v);
+    v += dpp_u32<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// number of set bits of `mask` strictly below this lane
+__device__ __forceinline__ int mbcnt(uint64_t mask) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0));
+}
+
+__device__ __forceinline__ float bcast_lane(float v, int lane) {   // lane must be wave-uniform
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ int bcast_lane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+
+// ---- specified fp32 exp / sigmoid: one rounding per listed operation, no FMA -------------------
+// k = rint(x*LOG2E); r = (x - k*LN2_HI) - k*LN2_LO; Horner degree-5 on r, times r*r, + r, + 1;
+// result = (p * 2^k1) * 2^k2 with k1 = trunc(k/2), k2 = k - k1.  x > EXP_HI -> inf, x < EXP_LO -> 0.
+__device__ __forceinline__ float spec_expf(float x) {
+    const float LOG2E = 1.44269504088896341f, LN2_HI = 0.693359375f, LN2_LO = -2.12194440e-4f;
+    const float EXP_HI = 88.72283935546875f, EXP_LO = -103.97208404541015625f;
+    float xc = fminf(fmaxf(x, EXP_LO), EXP_HI);
+    float k = __builtin_rintf(xc * LOG2E);
+    float r = xc - k * LN2_HI;
+    r = r - k * LN2_LO;
+    float p = 1.9875691500e-4f * r + 1.3981999507e-3f;
+    p = p * r + 8.3334519073e-3f;
+    p = p * r + 4.1665795894e-2f;
+    p = p * r + 1.6666665459e-1f;
+    p = p * r + 5.0000001201e-1f;
+    float rr = r * r;
+    p = p * rr + r;
+    p = p + 1.0f;
+    int ki = (int)k;
+    int k1 = ki / 2;
+    int k2 = ki - k1;
+    float t = p * u2f((uint32_t)(k1 + 127) << 23);
+    t = t * u2f((uint32_t)(k2 + 127) << 23);
+    t = (x > EXP_HI) ? __builtin_inff() : t;
+    t = (x < EXP_LO) ? 0.0f : t;
+    t = (x != x) ? x : t;
+    return t;
+}
+
+__device__ __forceinline__ float spec_sigmoidf(float x) {
+    float e = spec_expf(-x);
+    float d = 1.0f + e;
+    return 1.0f / d;
+}
+
+// ---- IoU exactly as torchvision.ops.boxes.box_iou computes one (gt, anchor) entry -------------
+// inter = clamp(min(x2)-max(x1),0) * clamp(min(y2)-max(y1),0); union = (area_gt + area_a) - inter
+__device__ __forceinline__ float iou_pair(float gx1, float gy1, float gx2, float gy2, float garea,
+                                          float ax1, float ay1, float ax2, float ay2, float aarea) {
+    float w = fmaxf(fminf(gx2, ax2) - fmaxf(gx1, ax1), 0.0f);
+    float h = fmaxf(fminf(gy2, ay2) - fmaxf(gy1, ay1), 0.0f);
+    float inter = w * h;
+    float uni = (garea + aarea) - inter;
+    return inter / uni;
+}
+
+__device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2) {
+    return (x2 - x1) * (y2 - y1);
+}
+
+}  // namespace od

@@ -1,0 +1,285 @@
+"""Tensor-level launchers for the HIP kernels of ``libod_boxes.so``.
+
+PyTorch is used here only for device memory (outputs and workspaces are ``torch.empty`` tensors on
+the inputs' device) and for the current HIP stream.  Every function requires tensors that live on
+a GPU; none of them has a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _C
+
+_workspaces: Dict[tuple, Tensor] = {}
+_small_cache: Dict[tuple, Tensor] = {}
+
+
+def _require_gpu(t: Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a GPU tensor: object_detection_amd has no CPU code path "
+                           f"(got device {t.device})")
+
+
+def _stream(device: torch.device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _workspace(device: torch.device, tag: str, nbytes: int) -> Tensor:
+    """Grow-only per-(device, tag) scratch buffer; torch returns 256-byte aligned blocks."""
+    key = (device.index, tag)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _f32c(t: Tensor) -> Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()          # fp16 anchors / head outputs are upcast exactly, like torchvision's _upcast
+    return t.contiguous()
+
+
+def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32) -> Tensor:
+    """Small host tuple -> device tensor, cached by value (avoids a host->device copy per call)."""
+    key = (device.index, dtype, tuple(int(v) for v in values))
+    t = _small_cache.get(key)
+    if t is None:
+        if len(_small_cache) > 4096:
+            _small_cache.clear()
+        t = torch.tensor(list(key[2]), dtype=dtype, device=device)
+        _small_cache[key] = t
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tuple[int, int]],
+                    cell_anchors: Sequence[Tensor], device: torch.device) -> Tensor:
+    """All pyramid anchors, [N,4] fp32 on ``device``, order (level, y, x, a)."""
+    L = len(grid_sizes)
+    I32 = ctypes.c_int32 * L
+    gh = I32(*[int(g[0]) for g in grid_sizes])
+    gw = I32(*[int(g[1]) for g in grid_sizes])
+    sh = I32(*[int(s[0]) for s in strides])
+    sw = I32(*[int(s[1]) for s in strides])
+    nb = I32(*[int(c.shape[0]) for c in cell_anchors])
+    base = torch.cat([c.detach().to("cpu", torch.float32).reshape(-1, 4) for c in cell_anchors]).contiguous()
+    n_total = sum(int(g[0]) * int(g[1]) * int(c.shape[0]) for g, c in zip(grid_sizes, cell_anchors))
+    out = torch.empty((n_total, 4), dtype=torch.float32, device=device)
+    rc = _C.lib().od_anchor_generate(gh, gw, sh, sw, nb, ctypes.c_void_p(base.data_ptr()), L, _ptr(out), n_total,
+                                     _stream(device))
+    _C.check(rc, "od_anchor_generate")
+    return out
+
+
+def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, Tensor, int]:
+    counts = [int(g.shape[0]) for g in gt_list]
+    offsets = [0]
+    for c in counts:
+        offsets.append(offsets[-1] + c)
+    m_total = offsets[-1]
+    if m_total > 0:
+        gt = torch.cat([_f32c(g.reshape(-1, 4)) for g in gt_list if g.shape[0] > 0]).contiguous()
+    else:
+        gt = torch.zeros((1, 4), dtype=torch.float32, device=device)
+    return gt, _device_ints(offsets, device), m_total
+
+
+def match_retinanet(anchors: Tensor, gt_list: Sequence[Tensor], high: float, low: float,
+                    allow_low_quality: bool = True) -> Tensor:
+    """Fused box_iou + Matcher.  anchors [N,4] (shared) or [B,N,4]; returns int64 [B,N]."""
+    _require_gpu(anchors, "anchors")
+    dev = anchors.device
+    anchors = _f32c(anchors)
+    B = len(gt_list)
+    if anchors.dim() == 3:
+        n, stride = anchors.shape[1], anchors.shape[1]
+    else:
+        n, stride = anchors.shape[0], 0
+    gt, offsets, m_total = _pack_gt(gt_list, dev)
+    _require_gpu(gt, "target boxes")
+    matched = torch.empty((B, n), dtype=torch.int64, device=dev)
+    lib = _C.lib()
+    nbytes = lib.od_match_retinanet_workspace_bytes(m_total, B)
+    ws = _workspace(dev, "match", nbytes)
+    rc = lib.od_match_retinanet(_ptr(anchors), stride, n, _ptr(gt), _ptr(offsets), m_total, B, float(high),
+                                float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws), ws.numel(),
+                                _stream(dev))
+    _C.check(rc, "od_match_retinanet")
+    return matched
+
+
+def match_fcos(anchors: Tensor, gt_list: Sequence[Tensor], n_first_level: int, n_last_level: int,
+               center_sampling_radius: float) -> Tensor:
+    _require_gpu(anchors, "anchors")
+    dev = anchors.device
+    anchors = _f32c(anchors)
+    B = len(gt_list)
+    if anchors.dim() == 3:
+        n, stride = anchors.shape[1], anchors.shape[1]
+    else:
+        n, stride = anchors.shape[0], 0
+    gt, offsets, _ = _pack_gt(gt_list, dev)
+    matched = torch.empty((B, n), dtype=torch.int64, device=dev)
+    rc = _C.lib().od_match_fcos(_ptr(anchors), stride, n, int(n_first_level), int(n_last_level), _ptr(gt),
+                                _ptr(offsets), B, float(center_sampling_radius), _ptr(matched), _stream(dev))
+    _C.check(rc, "od_match_fcos")
+    return matched
+
+
+def box_iou(boxes1: Tensor, boxes2: Tensor) -> Tensor:
+    _require_gpu(boxes1, "boxes1")
+    _require_gpu(boxes2, "boxes2")
+    b1, b2 = _f32c(boxes1), _f32c(boxes2)
+    m, n = b1.shape[0], b2.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=b1.device)
+    for r0 in range(0, max(m, 1), 65535):          # grid.y limit
+        r1 = min(m, r0 + 65535)
+        if r1 <= r0:
+            break
+        rc = _C.lib().od_box_iou(_ptr(b1[r0:r1]), r1 - r0, _ptr(b2), n, _ptr(out[r0:r1]), _stream(b1.device))
+        _C.check(rc, "od_box_iou")
+    return out
+
+
+def matcher(quality: Tensor, high: float, low: float, allow_low_quality: bool) -> Tensor:
+    _require_gpu(quality, "match_quality_matrix")
+    q = _f32c(quality)
+    m, n = q.shape
+    dev = q.device
+    out = torch.empty((n,), dtype=torch.int64, device=dev)
+    lib = _C.lib()
+    ws = _workspace(dev, "matcher", lib.od_matcher_workspace_bytes(m, n))
+    rc = lib.od_matcher(_ptr(q), m, n, float(high), float(low), int(bool(allow_low_quality)), _ptr(out), _ptr(ws),
+                        ws.numel(), _stream(dev))
+    _C.check(rc, "od_matcher")
+    return out
+
+
+def decode_boxes(rel_codes: Tensor, boxes: Tensor, coder: int, bbox_xform_clip: float,
+                 clip_hw: Optional[Tuple[int, int]] = None) -> Tensor:
+    _require_gpu(rel_codes, "rel_codes")
+    rel, bx = _f32c(rel_codes.reshape(-1, 4)), _f32c(boxes.reshape(-1, 4))
+    out = torch.empty_like(rel)
+    ch, cw = (float(clip_hw[0]), float(clip_hw[1])) if clip_hw is not None else (0.0, 0.0)
+    rc = _C.lib().od_decode_boxes(_ptr(rel), _ptr(bx), rel.shape[0], int(coder), float(bbox_xform_clip), ch, cw,
+                                  _ptr(out), _stream(rel.device))
+    _C.check(rc, "od_decode_boxes")
+    return out
+
+
+class SelectPlan:
+    """Host-side argument block of od_select_candidates for one pyramid geometry, built once."""
+
+    def __init__(self, level_sizes: Sequence[int], batch: int, num_classes: int, device: torch.device):
+        self.L = len(level_sizes)
+        self.level_sizes = [int(s) for s in level_sizes]
+        self.batch, self.num_classes, self.device = int(batch), int(num_classes), device
+        self.P = ctypes.c_void_p * self.L
+        self.I64 = ctypes.c_int64 * self.L
+        self.sizes = self.I64(*self.level_sizes)
+        self.ws_bytes = _C.lib().od_select_candidates_workspace_bytes(self.sizes, self.L, self.batch, self.num_classes)
+        if self.ws_bytes == 0 and self.batch > 0:
+            raise _C.OdBoxesError("od_select_candidates_workspace_bytes: shape outside the library limits")
+
+
+_plans: Dict[tuple, SelectPlan] = {}
+
+
+def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor], anchor_levels: Sequence[Tensor],
+                      image_hw: Tensor, score_thresh: float, topk: int, coder: int, bbox_xform_clip: float,
+                      ctr_levels: Optional[Sequence[Tensor]] = None, want_index: bool = False):
+    """Score filter + top-k + decode + clip for all (image, level).
+
+    cls_levels[l]: [B, N_l, C]; reg_levels[l]: [B, N_l, 4]; anchor_levels[l]: [N_l, 4] (shared by the
+    batch) or [B, N_l, 4]; ctr_levels[l]: [B, N_l, 1] for FCOS.  Level tensors may be views of one
+    [B, N, .] tensor (inner dims contiguous).  Returns padded candidates, slot = level*topk + rank:
+    (boxes [B,L*K,4], scores [B,L*K], labels int32 [B,L*K], index int64 [B,L*K] or None, count int32 [B,L]).
+    """
+    L = len(cls_levels)
+    dev = cls_levels[0].device
+    _require_gpu(cls_levels[0], "cls_logits")
+    B, C = cls_levels[0].shape[0], cls_levels[0].shape[-1]
+    sizes = [int(t.shape[1]) for t in cls_levels]
+    key = (dev.index, tuple(sizes), B, C)
+    plan = _plans.get(key)
+    if plan is None:
+        plan = _plans[key] = SelectPlan(sizes, B, C, dev)
+
+    def prep(levels, inner):
+        out, strides = [], []
+        for t in levels:
+            if t.dtype != torch.float32:
+                t = t.float()
+            if t.dim() == 3 and not (t.stride(2) == 1 and t.stride(1) == inner):
+                t = t.contiguous()
+            out.append(t)
+            strides.append(int(t.stride(0)) if t.dim() == 3 else 0)
+        return out, strides
+
+    cls_t, cls_s = prep(cls_levels, C)
+    reg_t, reg_s = prep(reg_levels, 4)
+    anc_t, anc_s = prep(anchor_levels, 4)
+    anc_t = [a if a.dim() == 3 or a.is_contiguous() else a.contiguous() for a in anc_t]
+    if ctr_levels is not None:
+        ctr_t, ctr_s = prep(ctr_levels, 1)
+    K = int(topk)
+    cand_boxes = torch.empty((B, L * K, 4), dtype=torch.float32, device=dev)
+    cand_scores = torch.empty((B, L * K), dtype=torch.float32, device=dev)
+    cand_labels = torch.empty((B, L * K), dtype=torch.int32, device=dev)
+    cand_index = torch.empty((B, L * K), dtype=torch.int64, device=dev) if want_index else None
+    cand_count = torch.empty((B, L), dtype=torch.int32, device=dev)
+    ws = _workspace(dev, "select", plan.ws_bytes)
+    P, I64 = plan.P, plan.I64
+    rc = _C.lib().od_select_candidates(
+        P(*[t.data_ptr() for t in cls_t]), I64(*cls_s),
+        P(*[t.data_ptr() for t in ctr_t]) if ctr_levels is not None else None,
+        I64(*ctr_s) if ctr_levels is not None else None,
+        P(*[t.data_ptr() for t in reg_t]), I64(*reg_s),
+        P(*[t.data_ptr() for t in anc_t]), I64(*anc_s),
+        plan.sizes, L, B, C, _ptr(image_hw), float(score_thresh), K, int(coder), float(bbox_xform_clip),
+        _ptr(cand_boxes), _ptr(cand_scores), _ptr(cand_labels), _ptr(cand_index), _ptr(cand_count),
+        _ptr(ws), ws.numel(), _stream(dev))
+    _C.check(rc, "od_select_candidates")
+    return cand_boxes, cand_scores, cand_labels, cand_index, cand_count
+
+
+def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], seg_count: Tensor, seg_stride: int,
+                       segments_sorted: bool, iou_threshold: float, mode: int, max_keep: int,
+                       want_keep_idx: bool = True, want_labels: bool = True):
+    """boxes [B, num_seg*seg_stride, 4], scores [B, .], labels int32 [B, .] or None, seg_count int32 [B, num_seg]."""
+    _require_gpu(boxes, "boxes")
+    dev = boxes.device
+    B = boxes.shape[0]
+    num_seg = seg_count.shape[1]
+    boxes, scores = _f32c(boxes), _f32c(scores)
+    if labels is not None and labels.dtype != torch.int32:
+        labels = labels.to(torch.int32)
+    if labels is not None:
+        labels = labels.contiguous()
+    max_keep = int(max_keep)
+    keep_idx = torch.empty((B, max_keep), dtype=torch.int64, device=dev) if want_keep_idx else None
+    out_boxes = torch.empty((B, max_keep, 4), dtype=torch.float32, device=dev)
+    out_scores = torch.empty((B, max_keep), dtype=torch.float32, device=dev)
+    out_labels = torch.empty((B, max_keep), dtype=torch.int64, device=dev) if want_labels else None
+    out_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    lib = _C.lib()
+    nbytes = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
+    if nbytes == 0 and B > 0:
+        raise _C.OdBoxesError(f"od_batched_nms: {num_seg * seg_stride} boxes per image exceed the limit "
+                              f"of {_C.OD_MAX_NMS_BOXES}")
+    ws = _workspace(dev, "nms", nbytes)
+    rc = lib.od_batched_nms(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(seg_count.contiguous()), num_seg,
+                            int(seg_stride), int(bool(segments_sorted)), B, float(iou_threshold), int(mode), max_keep,
+                            _ptr(keep_idx), _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels), _ptr(out_count),
+                            _ptr(ws), ws.numel(), _stream(dev))
+    _C.check(rc, "od_batched_nms")
+    return keep_idx, out_boxes, out_scores, out_labels, out_count

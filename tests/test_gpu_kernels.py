@@ -1,0 +1,223 @@
+"""Parity of each HIP kernel (through the C ABI) against the CPU checkers, bit-exact for indices."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from object_detection_amd import _C, kernels, synthetic
+from oracle import c_oracle, spec_math, tv_reference as tv
+
+pytestmark = pytest.mark.gpu
+
+
+def _anchors_cpu(image, grids, sizes, ratios=(0.5, 1.0, 2.0)):
+    ag = tv.AnchorGenerator(sizes, (ratios,) * len(sizes))
+    return ag, ag.forward(image, [(g, g) for g in grids], 1)[0]
+
+
+def test_anchor_generate(device):
+    grids = (64, 32, 16, 8, 4)
+    sizes = synthetic.retinanet_anchor_sizes(5, 32)
+    ag, ref = _anchors_cpu((512, 512), grids, sizes)
+    out = kernels.anchor_generate([(g, g) for g in grids], [(512 // g, 512 // g) for g in grids], ag.cell_anchors, device)
+    assert out.shape == ref.shape == (49104, 4)
+    assert torch.equal(out.cpu(), ref)
+    # non-square grid / stride, single base anchor (FCOS style)
+    ag2 = tv.AnchorGenerator(((8,), (16,)), ((1.0,),) * 2)
+    ref2 = torch.cat(ag2.grid_anchors([(5, 7), (3, 4)], [(8, 9), (16, 17)]))
+    out2 = kernels.anchor_generate([(5, 7), (3, 4)], [(8, 9), (16, 17)], ag2.cell_anchors, device)
+    assert torch.equal(out2.cpu(), ref2)
+
+
+@pytest.mark.parametrize("m", [1, 7, 100, 700])
+def test_match_retinanet(device, m):
+    grids = (64, 32, 16, 8, 4)
+    ag, anchors = _anchors_cpu((512, 512), grids, synthetic.retinanet_anchor_sizes(5, 32))
+    gts = []
+    for b in range(3):
+        gen = torch.Generator().manual_seed(100 * m + b)
+        gts.append(synthetic.make_gt_boxes(m if b != 1 else max(0, m - 1), (512, 512), gen))
+    gts.append(torch.zeros((0, 4)))  # empty-target image
+    out = kernels.match_retinanet(anchors.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+    for b, g in enumerate(gts):
+        ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, True)
+        assert np.array_equal(out[b].numpy(), ref), f"image {b}"
+    ref_t = tv.retinanet_match(gts, [anchors] * len(gts), 0.6, 0.5)
+    for b in range(len(gts)):
+        assert torch.equal(out[b], ref_t[b])
+    out_nolq = kernels.match_retinanet(anchors.to(device), [gts[0].to(device)], 0.6, 0.5, False).cpu()
+    assert np.array_equal(out_nolq[0].numpy(), c_oracle.match_retinanet(gts[0].numpy(), anchors.numpy(), 0.6, 0.5, False))
+
+
+def test_match_retinanet_gt_without_overlap(device):
+    """A GT that overlaps no anchor has max IoU 0: torchvision then restores every anchor."""
+    ag, anchors = _anchors_cpu((128, 128), (16, 8), ((16,), (32,)), (1.0,))
+    gt = torch.tensor([[10., 10., 60., 60.], [5000., 5000., 5010., 5010.]])
+    out = kernels.match_retinanet(anchors.to(device), [gt.to(device)], 0.6, 0.5, True).cpu()[0]
+    ref = tv.retinanet_match([gt], [anchors], 0.6, 0.5)[0]
+    assert torch.equal(out, ref)
+    assert (out >= 0).all()
+
+
+def test_match_retinanet_kat(device):
+    # hand-derived: IoU([0,0,10,10],[5,5,15,15]) = 25/175
+    iou = kernels.box_iou(torch.tensor([[0., 0., 10., 10.]], device=device), torch.tensor([[5., 5., 15., 15.]], device=device))
+    assert iou.cpu().view(torch.int32).item() == 0x3E124925
+    q = torch.tensor([[.7, .55, .3, .2], [.1, .58, .45, 0.]], device=device)
+    assert kernels.matcher(q, 0.6, 0.5, True).cpu().tolist() == [0, 1, -1, -1]
+    assert kernels.matcher(q, 0.6, 0.5, False).cpu().tolist() == [0, -2, -1, -1]
+
+
+def test_matcher_matrix_random(device):
+    gen = torch.Generator().manual_seed(5)
+    q = torch.rand((37, 5000), generator=gen)
+    q[3, 100] = q[3].max()  # tie on a row maximum
+    out = kernels.matcher(q.to(device), 0.6, 0.5, True).cpu()
+    assert torch.equal(out, tv.Matcher(0.6, 0.5, True)(q.clone()))
+    a = torch.rand((50, 4), generator=gen) * 100
+    a[:, 2:] += a[:, :2]
+    b = torch.rand((3000, 4), generator=gen) * 100
+    b[:, 2:] += b[:, :2]
+    assert torch.equal(kernels.box_iou(a.to(device), b.to(device)).cpu(), tv.box_iou(a, b))
+
+
+@pytest.mark.parametrize("m", [1, 33, 200])
+def test_match_fcos(device, m):
+    grids = (64, 32, 16, 8, 4)
+    ag, anchors = _anchors_cpu((512, 512), grids, ((8,), (16,), (32,), (64,), (128,)), (1.0,))
+    npl = [g * g for g in grids]
+    gts = [synthetic.make_gt_boxes(m, (512, 512), torch.Generator().manual_seed(7 * m + b)) for b in range(2)]
+    gts.append(torch.zeros((0, 4)))
+    out = kernels.match_fcos(anchors.to(device), [g.to(device) for g in gts], npl[0], npl[-1], 1.5).cpu()
+    ref = tv.fcos_match(gts, [anchors] * 3, npl, 1.5)
+    for b in range(3):
+        assert torch.equal(out[b], ref[b]), f"image {b}"
+        assert np.array_equal(out[b].numpy(), c_oracle.match_fcos(gts[b].numpy(), anchors.numpy(), npl[0], npl[-1], 1.5))
+    assert (out[0] >= 0).any()
+
+
+def test_decode_boxes(device):
+    gen = torch.Generator().manual_seed(11)
+    anchors = torch.rand((4097, 4), generator=gen) * 500
+    anchors[:, 2:] += anchors[:, :2] + 1
+    rel = torch.randn((4097, 4), generator=gen)
+    rel[5, 2] = 5.0
+    rel[6, 3] = 100.0
+    rel[7, 2] = -120.0
+    clip = math.log(1000.0 / 16)
+    out = kernels.decode_boxes(rel.to(device), anchors.to(device), _C.CODER_BOXCODER, clip).cpu()
+    ref = c_oracle.decode_single(rel.numpy(), anchors.numpy(), clip)
+    assert np.array_equal(out.numpy().view(np.uint32), ref.view(np.uint32))
+    ref_spec = tv.BoxCoder().decode_single(rel, anchors, math="spec")
+    assert torch.equal(out, ref_spec)
+    ref_torch = tv.BoxCoder().decode_single(rel, anchors, math="torch")
+    assert torch.allclose(out, ref_torch, rtol=1e-5, atol=1e-4)
+    out_c = kernels.decode_boxes(rel.to(device), anchors.to(device), _C.CODER_BOXCODER, clip, (300, 400)).cpu()
+    assert torch.equal(out_c, tv.clip_boxes_to_image(ref_spec, (300, 400)))
+    out_l = kernels.decode_boxes(rel.to(device), anchors.to(device), _C.CODER_LINEAR, 0.0).cpu()
+    assert torch.equal(out_l, tv.BoxLinearCoder(True).decode(rel, anchors))
+
+
+def _random_boxes(n, gen, extent=400.0, wh=80.0):
+    xy = torch.rand((n, 2), generator=gen) * extent
+    sz = torch.rand((n, 2), generator=gen) * wh + 1
+    return torch.cat([xy, xy + sz], dim=1)
+
+
+@pytest.mark.parametrize("n,classes,extent", [(1, 1, 400), (65, 3, 100), (300, 1, 60), (1000, 4, 400), (1500, 5, 150), (6000, 4, 800)])
+def test_batched_nms(device, n, classes, extent):
+    gen = torch.Generator().manual_seed(n + classes)
+    boxes = _random_boxes(n, gen, float(extent))
+    scores = torch.rand(n, generator=gen)
+    scores[::7] = scores[0]        # ties in score
+    labels = torch.randint(0, classes, (n,), generator=gen)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    for mode, omode in ((_C.NMS_TRICK, 0), (_C.NMS_VANILLA, 1)):
+        for thr in (0.3, 0.5):
+            ref = c_oracle.batched_nms(boxes.numpy(), scores.numpy(), labels.numpy(), thr, omode)
+            keep, ob, os_, ol, oc = kernels.batched_nms_padded(boxes[None].to(device), scores[None].to(device),
+                                                               labels[None].to(device), cnt, n, False, thr, mode, n)
+            k = int(oc.item())
+            assert k == len(ref), (mode, thr, k, len(ref))
+            assert np.array_equal(keep[0, :k].cpu().numpy(), ref), (mode, thr)
+            assert torch.equal(ob[0, :k].cpu(), boxes[ref])
+            assert torch.equal(os_[0, :k].cpu(), scores[ref])
+            assert torch.equal(ol[0, :k].cpu(), labels[ref])
+            # capped: first D of the same list
+            d = max(1, min(50, len(ref) // 2))
+            keep2, _, _, _, oc2 = kernels.batched_nms_padded(boxes[None].to(device), scores[None].to(device),
+                                                            labels[None].to(device), cnt, n, False, thr, mode, d)
+            assert int(oc2.item()) == min(d, len(ref))
+            assert np.array_equal(keep2[0, :int(oc2.item())].cpu().numpy(), ref[:d])
+    # torch restatement agrees with the C restatement on this input
+    t_keep = tv.batched_nms(boxes, scores, labels, 0.5, "cpu")
+    o_keep = c_oracle.batched_nms(boxes.numpy(), scores.numpy(), labels.numpy(), 0.5, 1 if 4 * n > 4000 else 0)
+    assert np.array_equal(t_keep.numpy(), o_keep)
+
+
+def test_nms_kat_and_degenerate(device):
+    b = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.]])
+    s = torch.tensor([.9, .8, .7])
+    cnt = torch.tensor([[3]], dtype=torch.int32, device=device)
+    keep, _, _, _, oc = kernels.batched_nms_padded(b[None].to(device), s[None].to(device), None, cnt, 3, False, 0.5,
+                                                   _C.NMS_TRICK, 3)
+    assert keep[0, :int(oc.item())].cpu().tolist() == [0, 2]
+    # zero-area pair: IoU = 0/0 = NaN never suppresses
+    z = torch.tensor([[5., 5., 5., 5.], [5., 5., 5., 5.]])
+    cnt2 = torch.tensor([[2]], dtype=torch.int32, device=device)
+    keep, _, _, _, oc = kernels.batched_nms_padded(z[None].to(device), torch.tensor([[.5, .4]], device=device), None,
+                                                   cnt2, 2, False, 0.5, _C.NMS_TRICK, 2)
+    assert keep[0, :int(oc.item())].cpu().tolist() == [0, 1]
+    # IoU exactly float(thr): CPU semantics compare the float IoU against the DOUBLE threshold -> suppressed
+    # boxes [0,0,10,10] and [0,0,10,3]: inter 30, union 100 -> 0.3f > 0.3 (double)
+    e = torch.tensor([[0., 0., 10., 10.], [0., 0., 10., 3.]])
+    keep, _, _, _, oc = kernels.batched_nms_padded(e[None].to(device), torch.tensor([[.9, .8]], device=device), None,
+                                                   cnt2, 2, False, 0.3, _C.NMS_TRICK, 2)
+    assert keep[0, :int(oc.item())].cpu().tolist() == c_oracle.nms(e.numpy(), np.float32([.9, .8]), 0.3).tolist() == [0]
+    # empty image
+    cnt0 = torch.tensor([[0]], dtype=torch.int32, device=device)
+    _, _, _, _, oc = kernels.batched_nms_padded(e[None].to(device), torch.tensor([[.9, .8]], device=device), None,
+                                                cnt0, 2, False, 0.3, _C.NMS_TRICK, 2)
+    assert int(oc.item()) == 0
+
+
+@pytest.mark.parametrize("coder", ["retinanet", "fcos"])
+def test_select_candidates(device, coder):
+    cfg = synthetic.CFG1
+    head = synthetic.make_head_outputs(cfg, with_ctrness=(coder == "fcos"))
+    sizes = synthetic.level_sizes(cfg)
+    ag, anchors = _anchors_cpu(cfg.image_size, cfg.grids, synthetic.retinanet_anchor_sizes(5, 32))
+    anchors_l = list(anchors.split(sizes))
+    cls_l = list(head["cls_logits"].split(sizes, dim=1))
+    reg_l = list(head["bbox_regression"].split(sizes, dim=1))
+    ctr_l = list(head["bbox_ctrness"].split(sizes, dim=1)) if coder == "fcos" else None
+    hw = torch.tensor([[512, 512], [480, 500]], dtype=torch.int32, device=device)
+    K, thr = 1000, (0.5 if coder == "retinanet" else 0.2)
+    code = _C.CODER_BOXCODER if coder == "retinanet" else _C.CODER_LINEAR
+    dev = lambda ts: [t.to(device) for t in ts]
+    cls_d = head["cls_logits"].to(device)
+    reg_d = head["bbox_regression"].to(device)
+    cb, cs, cl, ci, cc = kernels.select_candidates(
+        list(cls_d.split(sizes, dim=1)), list(reg_d.split(sizes, dim=1)), dev(anchors_l), hw, thr, K, code,
+        math.log(1000.0 / 16), ctr_levels=dev(ctr_l) if ctr_l else None, want_index=True)
+    cb, cs, cl, ci, cc = cb.cpu(), cs.cpu(), cl.cpu(), ci.cpu(), cc.cpu()
+    shapes = [(512, 512), (480, 500)]
+    for b in range(cfg.batch):
+        for l in range(len(sizes)):
+            s_ref, i_ref = c_oracle.filter_topk(cls_l[l][b].numpy(), ctr_l[l][b].numpy() if ctr_l else None,
+                                                cfg.num_classes, thr, K)
+            n = int(cc[b, l])
+            assert n == len(s_ref), (b, l, n, len(s_ref))
+            sl = slice(l * K, l * K + n)
+            assert np.array_equal(ci[b, sl].numpy(), i_ref), (b, l)
+            assert np.array_equal(cs[b, sl].numpy().view(np.uint32), s_ref.view(np.uint32))
+            a_idx = torch.from_numpy(i_ref // cfg.num_classes)
+            assert np.array_equal(cl[b, sl].numpy(), i_ref % cfg.num_classes)
+            if coder == "retinanet":
+                bx = tv.BoxCoder().decode_single(reg_l[l][b][a_idx], anchors_l[l][a_idx], math="spec")
+            else:
+                bx = tv.BoxLinearCoder(True).decode(reg_l[l][b][a_idx], anchors_l[l][a_idx])
+            bx = tv.clip_boxes_to_image(bx, shapes[b])
+            assert torch.equal(cb[b, sl], bx), (b, l)
+    assert int(cc[:, 0].min()) == K   # the finest level saturates top-k (ties at score 1.0 included)
