@@ -1,0 +1,257 @@
+#!/usr/bin/env python3
+"""Benchmark of the detection-head box pipeline on MI355X.
+
+One *step* = one pass of the hot path over one synthetic batch that is already resident in HBM:
+  training side : anchor <-> GT matching for the batch (fused box_iou + Matcher, M GT boxes/image)
+  inference side: score filter + top-k + decode + clip + class-batched NMS (+ detections all-gather
+                  over RCCL when more than one rank runs)
+through the model API (``RetinaNet.match_anchors`` / ``RetinaNet.postprocess_detections``).
+Workload = BASELINE.json configs[1]: RetinaNet, 1024x1024, P2-P7, 9 anchors/location (786,240
+anchors/image), 4 classes, topk_candidates=1000, detections_per_img=500, nms_thresh=0.3,
+score_thresh=0.5, batch 16 per GPU (weak scaling: every rank processes its own 16 images).
+
+Prints ONE JSON line (rank 0): images/s over all ranks, plus ``roofline`` for the dominant kernel
+(its duration measured with HIP events on the launch stream during the timed steps) and
+``cpu_baseline`` (the CPU restatement of the reference path timed on a bounded sample, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from object_detection_amd import _C, kernels, sharding, synthetic  # noqa: E402
+from object_detection_amd.retinanet_model import get_model  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
+    """Minimal bytes one launch must move (per batch of cfg.batch images); formulas in DESIGN.md."""
+    B, N, C, M = cfg.batch, cfg.num_anchors, cfg.num_classes, cfg.num_gt
+    L, K, D = len(cfg.grids), cfg.topk_candidates, cfg.detections_per_img
+    return {
+        "filter": 4.0 * B * N * C,                       # every logit read once
+        "select": 12.0 * B * L * K + 48.0 * B * L * K,   # candidate keys + (reg, anchor, box out)
+        "match_gtmax": B * (16.0 * N + 16.0 * M),        # anchors + GT read
+        "match_assign": B * (16.0 * N + 16.0 * M + 8.0 * N),   # + int64 matched index written
+        "nms": B * (28.0 * n_cand_per_image + 8.0 * D),
+        "anchor": 16.0 * N,
+    }.get(kernel, 0.0)
+
+
+def build_inputs(cfg, rank: int, dev):
+    """Synthetic batch, generated on the CPU from fixed seeds, then copied to the device."""
+    shifted = dataclasses.replace(cfg, cfg_id=cfg.cfg_id + 100 * rank)   # different images per rank
+    head = synthetic.make_head_outputs(shifted)
+    targets = synthetic.make_targets(shifted, empty_image=cfg.batch - 1)
+    head = {k: v.to(dev) for k, v in head.items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    return head, targets
+
+
+def cpu_baseline(cfg, sample_images: int):
+    """Reference CPU path (restated in oracle/tv_reference.py, torch ops, all host threads) on a
+    bounded sample of the same workload: `sample_images` images of match + postprocess."""
+    from oracle import tv_reference as tv
+    sizes = synthetic.level_sizes(cfg)
+    ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
+    anchors = ag.forward(cfg.image_size, [(g, g) for g in cfg.grids], 1)[0]
+    head = synthetic.make_head_outputs(cfg, images=range(sample_images))
+    targets = synthetic.make_targets(cfg)[:sample_images]
+    split = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+    anchors_l = list(anchors.split(sizes))
+    t0 = time.perf_counter()
+    tv.retinanet_match([t["boxes"] for t in targets], [anchors] * sample_images, cfg.fg_iou_thresh, cfg.bg_iou_thresh)
+    t1 = time.perf_counter()
+    tv.retinanet_postprocess(split, [anchors_l] * sample_images, [cfg.image_size] * sample_images, cfg.score_thresh,
+                             cfg.topk_candidates, cfg.nms_thresh, cfg.detections_per_img, math="torch",
+                             device_rule="cpu")
+    t2 = time.perf_counter()
+    return {
+        "value": sample_images / (t2 - t0),
+        "unit": "images/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"{sample_images} images of the same workload (match {t1 - t0:.2f} s + postprocess {t2 - t1:.2f} s), "
+                  f"torch CPU ops, {torch.get_num_threads()} threads",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-sample", type=int, default=3, help="images in the CPU-baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    cfg = synthetic.CFG2
+    L = len(cfg.grids)
+    model = get_model(cfg.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
+                      score_thresh=cfg.score_thresh, nms_thresh=cfg.nms_thresh,
+                      topk_candidates=cfg.topk_candidates, detections_per_img=cfg.detections_per_img,
+                      fg_iou_thresh=cfg.fg_iou_thresh, bg_iou_thresh=cfg.bg_iou_thresh,
+                      min_size=cfg.image_size[0], max_size=cfg.image_size[0]).to(dev).eval()
+    sizes = synthetic.level_sizes(cfg)
+    grids = [(g, g) for g in cfg.grids]
+    strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
+    anchors_l = model.anchor_generator.grid_anchors(grids, strides, dev)
+    anchors_flat = torch.cat(anchors_l) if len(anchors_l) > 1 else anchors_l[0]
+    assert anchors_flat.shape[0] == cfg.num_anchors
+    head, targets = build_inputs(cfg, rank, dev)
+    split = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+    shapes = [cfg.image_size] * cfg.batch
+    anchors_per_image = [anchors_flat] * cfg.batch
+    split_anchors = [anchors_l] * cfg.batch
+
+    def step():
+        matched = model.match_anchors(targets, anchors_per_image)
+        ob, os_, ol, oc = model_postprocess()
+        if world > 1:
+            packed = sharding.pack_detections(ob, os_, ol)
+            sharding.all_gather_detections(packed, oc)
+        return matched, oc
+
+    from object_detection_amd.retinanet import postprocess_batched
+
+    def model_postprocess():
+        # model.postprocess_detections without the final per-image slicing; the device->host read of
+        # the counts (which the list-of-dicts API needs) is kept so that every step is complete
+        out = postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
+                                  model.score_thresh, model.topk_candidates, model.nms_thresh,
+                                  model.detections_per_img, _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip,
+                                  return_padded=True)
+        out[3].tolist()
+        return out
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    sync()
+
+    # which kernel dominates?  (untimed probe with every launch bracketed)
+    _C.profile_select(_C.PROFILE_ALL)
+    for k in range(len(_C.KERNEL_NAMES)):
+        _C.profile_read(k)
+    for _ in range(3):
+        _, oc = step()
+    torch.cuda.synchronize(dev)
+    probe = {}
+    for k, name in enumerate(_C.KERNEL_NAMES):
+        ms, n = _C.profile_read(k)
+        if n:
+            probe[name] = {"ms_per_launch": ms / n, "launches_per_step": n / 3}
+    n_cand = float(kernels_candidates_per_image(cfg, split, split_anchors, shapes, model))
+    dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"])
+    dom_id = _C.KERNEL_NAMES.index(dominant)
+    _C.profile_select(dom_id)
+    _C.profile_read(dom_id)
+
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    dom_ms, dom_n = _C.profile_read(dom_id)
+    _C.profile_select(_C.PROFILE_OFF)
+
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        images = cfg.batch * world * args.steps
+        dur_s = (dom_ms / max(dom_n, 1)) * 1e-3
+        abytes = algorithmic_bytes(cfg, dominant, n_cand)
+        achieved = abytes / dur_s / 1e9 if dur_s > 0 else 0.0
+        for name, p in probe.items():
+            b = algorithmic_bytes(cfg, name, n_cand)
+            p["algorithmic_MB"] = b / 1e6
+            p["GBps"] = b / (p["ms_per_launch"] * 1e-3) / 1e9 if p["ms_per_launch"] > 0 else 0.0
+        result = {
+            "metric": "images/sec (match+decode+NMS) at 1024^2 bs16",
+            "value": images / elapsed,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[1]: RetinaNet 1024x1024 P2-P7 x9 anchors (786240/image), C=4, "
+                            "topk_candidates=1000, detections_per_img=500, nms_thresh=0.3, score_thresh=0.5; "
+                            f"step = match ({cfg.num_gt} GT/image, fg .6 / bg .5) + postprocess",
+                "batch_per_gpu": cfg.batch,
+                "global_batch": cfg.batch * world,
+                "anchors_per_image": cfg.num_anchors,
+                "candidates_per_image": n_cand,
+                "parallelism": f"image-sharded x{world}" + (", all-gather of detections (RCCL)" if world > 1 else ""),
+            },
+            "roofline": {
+                "kernel": dominant,
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launch_us": dur_s * 1e6,
+                "algorithmic_MB_per_launch": abytes / 1e6,
+            },
+            "kernels": probe,
+        }
+        if world == 1 and args.cpu_sample > 0:
+            result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
+        print(json.dumps(result))
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def kernels_candidates_per_image(cfg, split, split_anchors, shapes, model) -> float:
+    """Average number of NMS candidates per image (after score filter + top-k), for byte accounting."""
+    from object_detection_amd.retinanet import _image_hw_tensor, _shared_levels
+    dev = split["cls_logits"][0].device
+    _, _, _, _, cc = kernels.select_candidates(split["cls_logits"], split["bbox_regression"], _shared_levels(split_anchors),
+                                               _image_hw_tensor(shapes, dev), model.score_thresh, model.topk_candidates,
+                                               _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip)
+    return float(cc.sum().item()) / cfg.batch
+
+
+if __name__ == "__main__":
+    main()

@@ -104,7 +104,8 @@ int od_matcher(const float* quality, int64_t m, int64_t n, float high, float low
 /*
  * Box decoding + clipping.  Replaces BoxCoder.decode_single / BoxLinearCoder.decode followed
  * (when clip_h > 0) by torchvision.ops.boxes.clip_boxes_to_image.  exp() is the library's specified
- * fp32 algorithm; rel_codes, boxes, out: fp32 [n,4].
+ * fp32 algorithm (Cody-Waite reduction + degree-6 polynomial, one rounding per operation, no FMA);
+ * rel_codes, boxes, out: fp32 [n,4].
  */
 int od_decode_boxes(const float* rel_codes, const float* boxes, int64_t n, int32_t coder,
                     float bbox_xform_clip, float clip_h, float clip_w, float* out, void* stream);
@@ -156,6 +157,29 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
                    double iou_threshold, int32_t mode, int32_t max_keep, int64_t* keep_idx, float* out_boxes,
                    float* out_scores, int64_t* out_labels, int32_t* out_count, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/*
+ * Per-kernel timing aid.  No counterpart in the reference (it has no profiling hooks); used by
+ * bench.py to measure a kernel's own duration on the stream it runs on.  od_profile_select makes the
+ * library bracket every later launch of that kernel (or of all kernels) with hipEvents;
+ * od_profile_read waits for those events, returns the summed elapsed milliseconds and the number of
+ * launches since the previous read, and resets the kernel's counters.
+ */
+#define OD_PROFILE_OFF (-1)
+#define OD_PROFILE_ALL (-2)
+#define OD_KERNEL_ANCHOR 0
+#define OD_KERNEL_MATCH_GTMAX 1     /* od_match_retinanet pass 1: per-GT maxima          */
+#define OD_KERNEL_MATCH_ASSIGN 2    /* od_match_retinanet pass 2: argmax/threshold/restore */
+#define OD_KERNEL_MATCH_FCOS 3
+#define OD_KERNEL_BOX_IOU 4
+#define OD_KERNEL_MATCHER 5         /* both kernels of od_matcher */
+#define OD_KERNEL_DECODE 6
+#define OD_KERNEL_FILTER 7          /* od_select_candidates: score filter stream          */
+#define OD_KERNEL_SELECT 8          /* od_select_candidates: top-k + decode + clip        */
+#define OD_KERNEL_NMS 9
+#define OD_KERNEL_COUNT 10
+int od_profile_select(int32_t kernel_id);
+int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus
 }

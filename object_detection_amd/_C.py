@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes
 import os
+
+import torch  # noqa: F401  -- must be loaded first: libod_boxes.so has to bind to the HIP runtime torch uses
 from ctypes import c_double, c_float, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -44,7 +46,13 @@ SIGNATURES = {
     "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "od_profile_select": (c_int32, [c_int32]),
+    "od_profile_read": (c_int32, [c_int32, _P, _P]),
 }
+
+PROFILE_OFF, PROFILE_ALL = -1, -2
+KERNEL_NAMES = ["anchor", "match_gtmax", "match_assign", "match_fcos", "box_iou", "matcher", "decode", "filter",
+                "select", "nms"]
 
 _lib = None
 
@@ -77,3 +85,14 @@ def check(code: int, what: str) -> None:
     if code < 0:
         raise OdBoxesError(f"{what}: {_ERRORS.get(code, 'error')} (code {code})")
     raise OdBoxesError(f"{what}: HIP runtime error {code}")
+
+
+def profile_select(kernel_id: int) -> None:
+    check(lib().od_profile_select(int(kernel_id)), "od_profile_select")
+
+
+def profile_read(kernel_id: int):
+    """(total milliseconds, launches) of one kernel since the previous read; waits for its events."""
+    ms, n = c_double(0.0), c_int64(0)
+    check(lib().od_profile_read(int(kernel_id), ctypes.byref(ms), ctypes.byref(n)), "od_profile_read")
+    return ms.value, n.value

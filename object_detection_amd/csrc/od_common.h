@@ -22,7 +22,21 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
+// Launch `call` (a hipLaunchKernelGGL expression) as kernel `id`, bracketed by events when profiling selects it.
+#define OD_LAUNCH(id, stream, call)                        \
+    do {                                                   \
+        void* tok__ = nullptr;                             \
+        od::profile_begin((id), (stream), &tok__);         \
+        call;                                              \
+        od::profile_end(tok__, (stream));                  \
+        OD_LAUNCH_CHECK();                                 \
+    } while (0)
+
 namespace od {
+
+// optional event bracketing of kernel launches (od_profile.hip); token is null when not selected
+bool profile_begin(int kernel_id, hipStream_t s, void** token);
+void profile_end(void* token, hipStream_t s);
 
 constexpr int kWave = 64;
 

@@ -309,15 +309,15 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     dim3 grid((unsigned)((n + TILE - 1) / TILE), (unsigned)batch);
     if (allow_low_quality && m_total > 0) {
         OD_HIP(hipMemsetD32Async((hipDeviceptr_t)gt_max_key, (int)0x80000000u, (size_t)m_total, s));
-        hipLaunchKernelGGL(match_retinanet_kernel<1>, grid, dim3(MT), 0, s, (const float4*)anchors,
-                           (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes, gt_offsets,
-                           gt_max_key, high, low, 1, (long long*)matched);
-        OD_LAUNCH_CHECK();
+        OD_LAUNCH(OD_KERNEL_MATCH_GTMAX, s,
+                  hipLaunchKernelGGL(match_retinanet_kernel<1>, grid, dim3(MT), 0, s, (const float4*)anchors,
+                                     (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes,
+                                     gt_offsets, gt_max_key, high, low, 1, (long long*)matched));
     }
-    hipLaunchKernelGGL(match_retinanet_kernel<2>, grid, dim3(MT), 0, s, (const float4*)anchors,
-                       (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes, gt_offsets,
-                       gt_max_key, high, low, allow_low_quality ? 1 : 0, (long long*)matched);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_MATCH_ASSIGN, s,
+              hipLaunchKernelGGL(match_retinanet_kernel<2>, grid, dim3(MT), 0, s, (const float4*)anchors,
+                                 (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes, gt_offsets,
+                                 gt_max_key, high, low, allow_low_quality ? 1 : 0, (long long*)matched));
     return OD_OK;
 }
 
@@ -332,11 +332,11 @@ extern "C" int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, 
     if (n_first_level < 0 || n_last_level < 0 || n_first_level > n || n_last_level > n) return OD_ERR_ARG;
     if (batch > 65535) return OD_ERR_LIMIT;
     dim3 grid((unsigned)((n + FT - 1) / FT), (unsigned)batch);
-    hipLaunchKernelGGL(match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream, (const float4*)anchors,
-                       (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
-                       (long long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius,
-                       (long long*)matched);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_MATCH_FCOS, (hipStream_t)stream,
+              hipLaunchKernelGGL(match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream, (const float4*)anchors,
+                                 (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
+                                 (long long)n_last_level, (const float4*)gt_boxes, gt_offsets,
+                                 center_sampling_radius, (long long*)matched));
     return OD_OK;
 }
 
@@ -347,9 +347,9 @@ extern "C" int od_box_iou(const float* boxes1, int64_t m, const float* boxes2, i
     if (((uintptr_t)boxes1 & 15) || ((uintptr_t)boxes2 & 15)) return OD_ERR_ARG;
     if (m > 65535) return OD_ERR_LIMIT;
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
-    hipLaunchKernelGGL(box_iou_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)boxes1,
-                       (long long)m, (const float4*)boxes2, (long long)n, out);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_BOX_IOU, (hipStream_t)stream,
+              hipLaunchKernelGGL(box_iou_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)boxes1,
+                                 (long long)m, (const float4*)boxes2, (long long)n, out));
     return OD_OK;
 }
 
@@ -368,11 +368,12 @@ extern "C" int od_matcher(const float* quality, int64_t m, int64_t n, float high
     if (m > 0x7fffffff) return OD_ERR_LIMIT;
     hipStream_t s = (hipStream_t)stream;
     float* rowmax = (float*)workspace;
-    hipLaunchKernelGGL(matcher_rowmax_kernel, dim3((unsigned)m), dim3(256), 0, s, quality, (long long)n, rowmax);
-    OD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(matcher_col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, quality,
-                       (long long)m, (long long)n, rowmax, high, low, allow_low_quality ? 1 : 0,
-                       (long long*)matches);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_MATCHER, s,
+              hipLaunchKernelGGL(matcher_rowmax_kernel, dim3((unsigned)m), dim3(256), 0, s, quality, (long long)n,
+                                 rowmax));
+    OD_LAUNCH(OD_KERNEL_MATCHER, s,
+              hipLaunchKernelGGL(matcher_col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, quality,
+                                 (long long)m, (long long)n, rowmax, high, low, allow_low_quality ? 1 : 0,
+                                 (long long*)matches));
     return OD_OK;
 }

@@ -476,15 +476,15 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
     sp.clip = bbox_xform_clip;
 
     if (lay.total_chunks > 0) {
-        hipLaunchKernelGGL(filter_kernel, dim3((unsigned)lay.total_chunks, (unsigned)batch), dim3(ST), 0, s, fp,
-                           seg_keys, seg_count);
-        OD_LAUNCH_CHECK();
+        OD_LAUNCH(OD_KERNEL_FILTER, s,
+                  hipLaunchKernelGGL(filter_kernel, dim3((unsigned)lay.total_chunks, (unsigned)batch), dim3(ST), 0, s,
+                                     fp, seg_keys, seg_count));
     }
-    hipLaunchKernelGGL(select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, sp,
-                       (int)num_levels, lay.total_chunks,
-                       (const unsigned long long*)seg_keys, (const int*)seg_count, image_hw, cand_boxes,
-                       cand_scores, cand_labels, (long long*)cand_index, cand_count);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_SELECT, s,
+              hipLaunchKernelGGL(select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, sp,
+                                 (int)num_levels, lay.total_chunks, (const unsigned long long*)seg_keys,
+                                 (const int*)seg_count, image_hw, cand_boxes, cand_scores, cand_labels,
+                                 (long long*)cand_index, cand_count));
     return OD_OK;
 }
 
@@ -495,9 +495,9 @@ extern "C" int od_decode_boxes(const float* rel_codes, const float* boxes, int64
     if (!rel_codes || !boxes || !out) return OD_ERR_ARG;
     if (((uintptr_t)rel_codes & 15) || ((uintptr_t)boxes & 15) || ((uintptr_t)out & 15)) return OD_ERR_ARG;
     if (coder != OD_CODER_BOXCODER && coder != OD_CODER_LINEAR) return OD_ERR_ARG;
-    hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float4*)rel_codes, (const float4*)boxes, (long long)n, (int)coder, bbox_xform_clip,
-                       clip_h, clip_w, (float4*)out);
-    OD_LAUNCH_CHECK();
+    OD_LAUNCH(OD_KERNEL_DECODE, (hipStream_t)stream,
+              hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                                 (const float4*)rel_codes, (const float4*)boxes, (long long)n, (int)coder,
+                                 bbox_xform_clip, clip_h, clip_w, (float4*)out));
     return OD_OK;
 }

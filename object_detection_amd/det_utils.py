@@ -1,0 +1,170 @@
+"""Matcher / box coders / loss helpers with the interfaces of
+``torchvision.models.detection._utils`` (0.16.2), which the reference's models are built from
+(``object_detection/retinanet/retinanet_model.py:4-7``).  Index-producing work runs in HIP kernels;
+differentiable loss arithmetic (downstream of matching) stays in PyTorch autograd.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _C, kernels
+
+
+class Matcher:
+    """Assigns to each prediction (column) a ground-truth row, -1 (below ``low_threshold``) or -2
+    (between the thresholds); optionally restores low-quality matches."""
+
+    BELOW_LOW_THRESHOLD = -1
+    BETWEEN_THRESHOLDS = -2
+
+    def __init__(self, high_threshold: float, low_threshold: float, allow_low_quality_matches: bool = False):
+        torch._assert(low_threshold <= high_threshold, "low_threshold should be <= high_threshold")
+        self.high_threshold = high_threshold
+        self.low_threshold = low_threshold
+        self.allow_low_quality_matches = allow_low_quality_matches
+
+    def __call__(self, match_quality_matrix: Tensor) -> Tensor:
+        if match_quality_matrix.numel() == 0:
+            if match_quality_matrix.shape[0] == 0:
+                raise ValueError("No ground-truth boxes available for one of the images during training")
+            raise ValueError("No proposal boxes available for one of the images during training")
+        return kernels.matcher(match_quality_matrix, self.high_threshold, self.low_threshold,
+                               self.allow_low_quality_matches)
+
+
+class BoxCoder:
+    """Centre/size delta coding.  ``decode_single`` without autograd runs the HIP kernel (specified
+    fp32 exp); when gradients are required it runs the same formulas as PyTorch ops."""
+
+    def __init__(self, weights: Tuple[float, float, float, float], bbox_xform_clip: float = math.log(1000.0 / 16)):
+        self.weights = weights
+        self.bbox_xform_clip = bbox_xform_clip
+
+    def encode_single(self, reference_boxes: Tensor, proposals: Tensor) -> Tensor:
+        wx, wy, ww, wh = self.weights
+        ex_w = proposals[:, 2] - proposals[:, 0]
+        ex_h = proposals[:, 3] - proposals[:, 1]
+        ex_cx = proposals[:, 0] + 0.5 * ex_w
+        ex_cy = proposals[:, 1] + 0.5 * ex_h
+        gt_w = reference_boxes[:, 2] - reference_boxes[:, 0]
+        gt_h = reference_boxes[:, 3] - reference_boxes[:, 1]
+        gt_cx = reference_boxes[:, 0] + 0.5 * gt_w
+        gt_cy = reference_boxes[:, 1] + 0.5 * gt_h
+        return torch.stack((wx * (gt_cx - ex_cx) / ex_w, wy * (gt_cy - ex_cy) / ex_h,
+                            ww * torch.log(gt_w / ex_w), wh * torch.log(gt_h / ex_h)), dim=1)
+
+    def decode_single(self, rel_codes: Tensor, boxes: Tensor) -> Tensor:
+        boxes = boxes.to(rel_codes.dtype)
+        needs_grad = torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad)
+        single = rel_codes.dim() == 2 and rel_codes.shape[1] == 4
+        if rel_codes.is_cuda and single and not needs_grad and rel_codes.dtype == torch.float32:
+            codes = rel_codes
+            if tuple(self.weights) != (1.0, 1.0, 1.0, 1.0):
+                codes = rel_codes / rel_codes.new_tensor(self.weights)   # same division torchvision performs
+            return kernels.decode_boxes(codes, boxes, _C.CODER_BOXCODER, self.bbox_xform_clip)
+        widths = boxes[:, 2] - boxes[:, 0]
+        heights = boxes[:, 3] - boxes[:, 1]
+        ctr_x = boxes[:, 0] + 0.5 * widths
+        ctr_y = boxes[:, 1] + 0.5 * heights
+        wx, wy, ww, wh = self.weights
+        dx = rel_codes[:, 0::4] / wx
+        dy = rel_codes[:, 1::4] / wy
+        dw = torch.clamp(rel_codes[:, 2::4] / ww, max=self.bbox_xform_clip)
+        dh = torch.clamp(rel_codes[:, 3::4] / wh, max=self.bbox_xform_clip)
+        pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
+        pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
+        half_w = 0.5 * (torch.exp(dw) * widths[:, None])
+        half_h = 0.5 * (torch.exp(dh) * heights[:, None])
+        return torch.stack((pred_ctr_x - half_w, pred_ctr_y - half_h, pred_ctr_x + half_w, pred_ctr_y + half_h),
+                           dim=2).flatten(1)
+
+
+class BoxLinearCoder:
+    """FCOS distance coding (left, top, right, bottom), optionally normalised by the anchor size."""
+
+    def __init__(self, normalize_by_size: bool = True):
+        self.normalize_by_size = normalize_by_size
+
+    def encode(self, reference_boxes: Tensor, proposals: Tensor) -> Tensor:
+        ctr_x = 0.5 * (reference_boxes[..., 0] + reference_boxes[..., 2])
+        ctr_y = 0.5 * (reference_boxes[..., 1] + reference_boxes[..., 3])
+        targets = torch.stack((ctr_x - proposals[..., 0], ctr_y - proposals[..., 1],
+                               proposals[..., 2] - ctr_x, proposals[..., 3] - ctr_y), dim=-1)
+        if self.normalize_by_size:
+            w = reference_boxes[..., 2] - reference_boxes[..., 0]
+            h = reference_boxes[..., 3] - reference_boxes[..., 1]
+            targets = targets / torch.stack((w, h, w, h), dim=-1)
+        return targets
+
+    def decode(self, rel_codes: Tensor, boxes: Tensor) -> Tensor:
+        boxes = boxes.to(dtype=rel_codes.dtype)
+        needs_grad = torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad)
+        if (rel_codes.is_cuda and not needs_grad and self.normalize_by_size and rel_codes.dtype == torch.float32
+                and rel_codes.shape == boxes.shape):
+            return kernels.decode_boxes(rel_codes, boxes, _C.CODER_LINEAR, 0.0).reshape(rel_codes.shape)
+        ctr_x = 0.5 * (boxes[..., 0] + boxes[..., 2])
+        ctr_y = 0.5 * (boxes[..., 1] + boxes[..., 3])
+        if self.normalize_by_size:
+            w = boxes[..., 2] - boxes[..., 0]
+            h = boxes[..., 3] - boxes[..., 1]
+            rel_codes = rel_codes * torch.stack((w, h, w, h), dim=-1)
+        return torch.stack((ctr_x - rel_codes[..., 0], ctr_y - rel_codes[..., 1],
+                            ctr_x + rel_codes[..., 2], ctr_y + rel_codes[..., 3]), dim=-1)
+
+
+def _topk_min(input: Tensor, orig_kval: int, axis: int) -> int:
+    return min(orig_kval, input.size(axis))
+
+
+# ---- loss helpers (autograd, PyTorch ops) ---------------------------------------------------------
+def sigmoid_focal_loss(inputs: Tensor, targets: Tensor, alpha: float = 0.25, gamma: float = 2,
+                       reduction: str = "none") -> Tensor:
+    p = torch.sigmoid(inputs)
+    ce = torch.nn.functional.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = p * targets + (1 - p) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+def generalized_box_iou_loss(boxes1: Tensor, boxes2: Tensor, reduction: str = "none", eps: float = 1e-7) -> Tensor:
+    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
+    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
+    xk1, yk1 = torch.max(x1, x1g), torch.max(y1, y1g)
+    xk2, yk2 = torch.min(x2, x2g), torch.min(y2, y2g)
+    inter = torch.zeros_like(x1)
+    mask = (yk2 > yk1) & (xk2 > xk1)
+    inter[mask] = (xk2[mask] - xk1[mask]) * (yk2[mask] - yk1[mask])
+    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
+    iou = inter / (union + eps)
+    area_c = (torch.max(x2, x2g) - torch.min(x1, x1g)) * (torch.max(y2, y2g) - torch.min(y1, y1g))
+    loss = 1 - (iou - ((area_c - union) / (area_c + eps)))
+    if reduction == "mean":
+        return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+def _box_loss(type: str, box_coder: BoxCoder, anchors_per_image: Tensor, matched_gt_boxes_per_image: Tensor,
+              bbox_regression_per_image: Tensor, cnf=None) -> Tensor:
+    torch._assert(type in ["l1", "smooth_l1", "giou"], f"Unsupported loss: {type}")
+    if type == "l1":
+        target = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
+        return torch.nn.functional.l1_loss(bbox_regression_per_image, target, reduction="sum")
+    if type == "smooth_l1":
+        target = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
+        beta = cnf["beta"] if cnf is not None and "beta" in cnf else 1.0
+        return torch.nn.functional.smooth_l1_loss(bbox_regression_per_image, target, reduction="sum", beta=beta)
+    pred = box_coder.decode_single(bbox_regression_per_image, anchors_per_image)
+    eps = torch.finfo(bbox_regression_per_image.dtype).eps
+    return generalized_box_iou_loss(pred, matched_gt_boxes_per_image, reduction="sum", eps=eps)

@@ -1,0 +1,278 @@
+"""RetinaNet with the constructor, attributes and method signatures of
+``torchvision.models.detection.retinanet`` (0.16.2), which the reference instantiates at
+``object_detection/retinanet/retinanet_model.py:47-54`` and calls at ``object_detection/train.py:62,84``
+and ``object_detection/predict.py:61``.
+
+The box pipeline of the model -- anchors, anchor/GT matching in ``compute_loss``, and the whole of
+``postprocess_detections`` -- runs in the HIP kernels of ``libod_boxes.so``, batched over images
+(no per-image / per-level Python loops, one device->host read per batch for the detection counts).
+Convolutional head layers and the loss arithmetic downstream of matching are ordinary PyTorch.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from collections import OrderedDict
+from functools import partial
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _C, boxes as box_ops, det_utils, kernels
+from .anchor_utils import AnchorGenerator
+from .transform import GeneralizedRCNNTransform
+
+
+def _sum(x: List[Tensor]) -> Tensor:
+    res = x[0]
+    for i in x[1:]:
+        res = res + i
+    return res
+
+
+def _conv_tower(in_channels: int, norm_layer: Optional[Callable[..., nn.Module]]) -> nn.Sequential:
+    """Four 3x3 conv (+norm) + ReLU blocks; block layout [conv, (norm), relu] keeps state-dict keys
+    ``conv.<i>.0.weight`` / ``conv.<i>.1.weight`` like torchvision's Conv2dNormActivation."""
+    blocks = []
+    for _ in range(4):
+        layers: List[nn.Module] = [nn.Conv2d(in_channels, in_channels, 3, 1, 1, bias=norm_layer is None)]
+        if norm_layer is not None:
+            layers.append(norm_layer(in_channels))
+        layers.append(nn.ReLU(inplace=True))
+        blocks.append(nn.Sequential(*layers))
+    tower = nn.Sequential(*blocks)
+    for m in tower.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.normal_(m.weight, std=0.01)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+    return tower
+
+
+def _to_anchor_major(x: Tensor, per_anchor: int) -> Tensor:
+    # (B, A*K, H, W) -> (B, H*W*A, K): memory order (h, w, a, k) equals the anchor order (y, x, a)
+    B, _, H, W = x.shape
+    return x.view(B, -1, per_anchor, H, W).permute(0, 3, 4, 1, 2).reshape(B, -1, per_anchor)
+
+
+class RetinaNetClassificationHead(nn.Module):
+    def __init__(self, in_channels, num_anchors, num_classes, prior_probability=0.01,
+                 norm_layer: Optional[Callable[..., nn.Module]] = None):
+        super().__init__()
+        self.conv = _conv_tower(in_channels, norm_layer)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors * num_classes, kernel_size=3, stride=1, padding=1)
+        nn.init.normal_(self.cls_logits.weight, std=0.01)
+        nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_probability) / prior_probability))
+        self.num_classes = num_classes
+        self.num_anchors = num_anchors
+        self.BETWEEN_THRESHOLDS = det_utils.Matcher.BETWEEN_THRESHOLDS
+
+    def compute_loss(self, targets, head_outputs, matched_idxs) -> Tensor:
+        losses = []
+        for t, logits, m in zip(targets, head_outputs["cls_logits"], matched_idxs):
+            fg = m >= 0
+            num_fg = fg.sum()
+            gt_classes_target = torch.zeros_like(logits)
+            gt_classes_target[fg, t["labels"][m[fg]]] = 1.0
+            valid = m != self.BETWEEN_THRESHOLDS
+            losses.append(det_utils.sigmoid_focal_loss(logits[valid], gt_classes_target[valid], reduction="sum")
+                          / max(1, num_fg))
+        return _sum(losses) / len(targets)
+
+    def forward(self, x: List[Tensor]) -> Tensor:
+        return torch.cat([_to_anchor_major(self.cls_logits(self.conv(f)), self.num_classes) for f in x], dim=1)
+
+
+class RetinaNetRegressionHead(nn.Module):
+    def __init__(self, in_channels, num_anchors, norm_layer: Optional[Callable[..., nn.Module]] = None):
+        super().__init__()
+        self.conv = _conv_tower(in_channels, norm_layer)
+        self.bbox_reg = nn.Conv2d(in_channels, num_anchors * 4, kernel_size=3, stride=1, padding=1)
+        nn.init.normal_(self.bbox_reg.weight, std=0.01)
+        nn.init.zeros_(self.bbox_reg.bias)
+        self.box_coder = det_utils.BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self._loss_type = "l1"
+
+    def compute_loss(self, targets, head_outputs, anchors, matched_idxs) -> Tensor:
+        losses = []
+        for t, reg, a, m in zip(targets, head_outputs["bbox_regression"], anchors, matched_idxs):
+            fg = torch.where(m >= 0)[0]
+            num_fg = fg.numel()
+            losses.append(det_utils._box_loss(self._loss_type, self.box_coder, a[fg, :], t["boxes"][m[fg]],
+                                              reg[fg, :]) / max(1, num_fg))
+        return _sum(losses) / max(1, len(targets))
+
+    def forward(self, x: List[Tensor]) -> Tensor:
+        return torch.cat([_to_anchor_major(self.bbox_reg(self.conv(f)), 4) for f in x], dim=1)
+
+
+class RetinaNetHead(nn.Module):
+    def __init__(self, in_channels, num_anchors, num_classes, norm_layer: Optional[Callable[..., nn.Module]] = None):
+        super().__init__()
+        self.classification_head = RetinaNetClassificationHead(in_channels, num_anchors, num_classes,
+                                                               norm_layer=norm_layer)
+        self.regression_head = RetinaNetRegressionHead(in_channels, num_anchors, norm_layer=norm_layer)
+
+    def compute_loss(self, targets, head_outputs, anchors, matched_idxs) -> Dict[str, Tensor]:
+        return {
+            "classification": self.classification_head.compute_loss(targets, head_outputs, matched_idxs),
+            "bbox_regression": self.regression_head.compute_loss(targets, head_outputs, anchors, matched_idxs),
+        }
+
+    def forward(self, x: List[Tensor]) -> Dict[str, Tensor]:
+        return {"cls_logits": self.classification_head(x), "bbox_regression": self.regression_head(x)}
+
+
+def _shared_levels(anchors: List[List[Tensor]]) -> Optional[List[Tensor]]:
+    """Per-level anchors if every image uses the same tensors (what AnchorGenerator hands out)."""
+    first = anchors[0]
+    for other in anchors[1:]:
+        for a, b in zip(first, other):
+            if a.data_ptr() != b.data_ptr() or a.shape != b.shape:
+                return None
+    return list(first)
+
+
+def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) -> Tensor:
+    flat = [int(v) for hw in image_shapes for v in hw]
+    return kernels._device_ints(flat, device).view(-1, 2)
+
+
+def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,
+                        detections_per_img, coder, bbox_xform_clip, ctr_levels=None, nms_mode=_C.NMS_AUTO_GPU,
+                        return_padded: bool = False):
+    """Shared tail of RetinaNet / FCOS postprocess_detections: two library calls for the whole batch."""
+    shared = _shared_levels(anchors)
+    if shared is None:
+        shared = [torch.stack([a[l] for a in anchors]) for l in range(len(anchors[0]))]
+    dev = cls_levels[0].device
+    hw = _image_hw_tensor(image_shapes, dev)
+    K = int(topk_candidates)
+    cb, cs, cl, _, cc = kernels.select_candidates(cls_levels, reg_levels, shared, hw, score_thresh, K, coder,
+                                                  bbox_xform_clip, ctr_levels=ctr_levels)
+    _, ob, os_, ol, oc = kernels.batched_nms_padded(cb, cs, cl, cc, K, True, nms_thresh, nms_mode,
+                                                    int(detections_per_img), want_keep_idx=False)
+    if return_padded:
+        return ob, os_, ol, oc
+    counts = oc.tolist()   # the one device->host read: detections are variable-length tensors
+    return [{"boxes": ob[i, :c], "scores": os_[i, :c], "labels": ol[i, :c]} for i, c in enumerate(counts)]
+
+
+class RetinaNet(nn.Module):
+    def __init__(self, backbone, num_classes, min_size=800, max_size=1333, image_mean=None, image_std=None,
+                 anchor_generator=None, head=None, proposal_matcher=None, score_thresh=0.05, nms_thresh=0.5,
+                 detections_per_img=300, fg_iou_thresh=0.5, bg_iou_thresh=0.4, topk_candidates=1000, **kwargs):
+        super().__init__()
+        if not hasattr(backbone, "out_channels"):
+            raise ValueError("backbone should contain an attribute out_channels specifying the number of "
+                             "output channels (assumed to be the same for all the levels)")
+        self.backbone = backbone
+        if not isinstance(anchor_generator, (AnchorGenerator, type(None))):
+            raise TypeError(f"anchor_generator should be of type AnchorGenerator or None instead of "
+                            f"{type(anchor_generator)}")
+        if anchor_generator is None:
+            sizes = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in [32, 64, 128, 256, 512])
+            anchor_generator = AnchorGenerator(sizes, ((0.5, 1.0, 2.0),) * len(sizes))
+        self.anchor_generator = anchor_generator
+        if head is None:
+            head = RetinaNetHead(backbone.out_channels, anchor_generator.num_anchors_per_location()[0], num_classes)
+        self.head = head
+        if proposal_matcher is None:
+            proposal_matcher = det_utils.Matcher(fg_iou_thresh, bg_iou_thresh, allow_low_quality_matches=True)
+        self.proposal_matcher = proposal_matcher
+        self.box_coder = det_utils.BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        if image_mean is None:
+            image_mean = [0.485, 0.456, 0.406]
+        if image_std is None:
+            image_std = [0.229, 0.224, 0.225]
+        self.transform = GeneralizedRCNNTransform(min_size, max_size, image_mean, image_std, **kwargs)
+        self.score_thresh = score_thresh
+        self.nms_thresh = nms_thresh
+        self.detections_per_img = detections_per_img
+        self.topk_candidates = topk_candidates
+        self._has_warned = False
+
+    # ---- training side: anchor / ground-truth matching ------------------------------------------------
+    def match_anchors(self, targets: List[Dict[str, Tensor]], anchors: List[Tensor]) -> List[Tensor]:
+        """matched_idxs per image: one fused box_iou+Matcher launch pair for the whole batch."""
+        pm = self.proposal_matcher
+        gts = [t["boxes"] for t in targets]
+        if isinstance(pm, det_utils.Matcher):
+            same = all(a.data_ptr() == anchors[0].data_ptr() and a.shape == anchors[0].shape for a in anchors)
+            anc = anchors[0] if same else torch.stack(list(anchors))
+            matched = kernels.match_retinanet(anc, gts, pm.high_threshold, pm.low_threshold,
+                                              pm.allow_low_quality_matches)
+            return list(matched.unbind(0))
+        out = []   # user-supplied matcher object: matrix form, image by image
+        for anchors_per_image, gt in zip(anchors, gts):
+            if gt.numel() == 0:
+                out.append(torch.full((anchors_per_image.size(0),), -1, dtype=torch.int64,
+                                      device=anchors_per_image.device))
+                continue
+            out.append(pm(box_ops.box_iou(gt, anchors_per_image)))
+        return out
+
+    def compute_loss(self, targets, head_outputs, anchors) -> Dict[str, Tensor]:
+        matched_idxs = self.match_anchors(targets, anchors)
+        return self.head.compute_loss(targets, head_outputs, anchors, matched_idxs)
+
+    # ---- inference side ------------------------------------------------------------------------------------
+    def postprocess_detections(self, head_outputs: Dict[str, List[Tensor]], anchors: List[List[Tensor]],
+                               image_shapes: List[Tuple[int, int]]) -> List[Dict[str, Tensor]]:
+        return postprocess_batched(head_outputs["cls_logits"], head_outputs["bbox_regression"], anchors,
+                                   image_shapes, self.score_thresh, self.topk_candidates, self.nms_thresh,
+                                   self.detections_per_img, _C.CODER_BOXCODER, self.box_coder.bbox_xform_clip)
+
+    def forward(self, images: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):
+        if self.training:
+            if targets is None:
+                torch._assert(False, "targets should not be none when in training mode")
+            else:
+                for target in targets:
+                    boxes = target["boxes"]
+                    torch._assert(isinstance(boxes, torch.Tensor), "Expected target boxes to be of type Tensor.")
+                    torch._assert(len(boxes.shape) == 2 and boxes.shape[-1] == 4,
+                                  f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
+        original_image_sizes: List[Tuple[int, int]] = []
+        for img in images:
+            val = img.shape[-2:]
+            torch._assert(len(val) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
+            original_image_sizes.append((int(val[0]), int(val[1])))
+        images, targets = self.transform(images, targets)
+        if targets is not None:
+            for target_idx, target in enumerate(targets):
+                boxes = target["boxes"]
+                degenerate = boxes[:, 2:] <= boxes[:, :2]
+                if degenerate.any():
+                    bb_idx = torch.where(degenerate.any(dim=1))[0][0]
+                    degen_bb: List[float] = boxes[bb_idx].tolist()
+                    torch._assert(False, "All bounding boxes should have positive height and width."
+                                  f" Found invalid box {degen_bb} for target at index {target_idx}.")
+        features = self.backbone(images.tensors)
+        if isinstance(features, torch.Tensor):
+            features = OrderedDict([("0", features)])
+        features = list(features.values())
+        head_outputs = self.head(features)
+        anchors = self.anchor_generator(images, features)
+        losses: Dict[str, Tensor] = {}
+        detections: List[Dict[str, Tensor]] = []
+        if self.training:
+            if targets is None:
+                torch._assert(False, "targets should not be none when in training mode")
+            else:
+                losses = self.compute_loss(targets, head_outputs, anchors)
+            return losses
+        num_anchors_per_level = [x.size(2) * x.size(3) for x in features]
+        HW = 0
+        for v in num_anchors_per_level:
+            HW += v
+        HWA = head_outputs["cls_logits"].size(1)
+        A = HWA // HW
+        num_anchors_per_level = [hw * A for hw in num_anchors_per_level]
+        split_head_outputs: Dict[str, List[Tensor]] = {}
+        for k in head_outputs:
+            split_head_outputs[k] = list(head_outputs[k].split(num_anchors_per_level, dim=1))
+        split_anchors = [list(a.split(num_anchors_per_level)) for a in anchors]
+        detections = self.postprocess_detections(split_head_outputs, split_anchors, images.image_sizes)
+        return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
