@@ -52,6 +52,14 @@ def _sigmoid(x: Tensor, mode: str) -> Tensor:
     return torch.from_numpy(spec_math.od_sigmoidf(x.detach().cpu().numpy())).reshape(x.shape)
 
 
+def _sqrt(x: Tensor, mode: str) -> Tensor:
+    # torch's CPU sqrt kernel is not correctly rounded on every build (it differs from IEEE sqrtf in
+    # ~0.6 % of fp32 inputs here); the specified pipeline uses the IEEE correctly rounded square root.
+    if mode == "torch":
+        return torch.sqrt(x)
+    return torch.from_numpy(np.sqrt(x.detach().cpu().numpy().astype(np.float32))).reshape(x.shape)
+
+
 # --------------------------------------------------------------------------------------------
 # torchvision/ops/boxes.py
 # --------------------------------------------------------------------------------------------
@@ -533,7 +541,7 @@ def fcos_postprocess(head_outputs: Dict[str, List[Tensor]], anchors: List[List[T
         image_boxes, image_scores, image_labels = [], [], []
         for reg_l, logits_l, ctr_l, anchors_l in zip(reg_pi, log_pi, ctr_pi, anchors_per_image):
             num_classes = logits_l.shape[-1]
-            scores_l = torch.sqrt(_sigmoid(logits_l, math) * _sigmoid(ctr_l, math)).flatten()
+            scores_l = _sqrt(_sigmoid(logits_l, math) * _sigmoid(ctr_l, math), math).flatten()
             keep_idxs = scores_l > score_thresh
             scores_l = scores_l[keep_idxs]
             topk_idxs = torch.where(keep_idxs)[0]

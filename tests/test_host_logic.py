@@ -1,0 +1,122 @@
+"""CPU: host-side mirror of the reference interface (no kernel launches)."""
+import pytest
+import torch
+
+from object_detection_amd import det_utils, sharding, synthetic
+from object_detection_amd.anchor_utils import AnchorGenerator
+from object_detection_amd.fcos import FCOS
+from object_detection_amd.retinanet import RetinaNet, RetinaNetHead
+from object_detection_amd.retinanet_model import PyramidStub, anchor_geometry, get_model
+from object_detection_amd.transform import GeneralizedRCNNTransform
+from oracle import tv_reference as tv
+
+
+def test_anchor_generator_cell_anchors_match_checker():
+    sizes = synthetic.retinanet_anchor_sizes(6)
+    ratios = ((0.5, 1.0, 2.0),) * 6
+    ag, ref = AnchorGenerator(sizes, ratios), tv.AnchorGenerator(sizes, ratios)
+    assert ag.num_anchors_per_location() == [9] * 6
+    for a, b in zip(ag.cell_anchors, ref.cell_anchors):
+        assert torch.equal(a, b)
+    with pytest.raises(AssertionError):
+        ag.grid_anchors([(4, 4)], [(8, 8)], torch.device("cpu"))   # level-count mismatch (reference quirk 2)
+
+
+def test_get_model_signature_and_kwargs():
+    # the call of the reference's train.py:144, including the misspelt nms_thres= it forwards
+    m = get_model(4, min_size=1024, max_size=1024, pretrained=False, arch="retinanet", backbone="pyramid_stub",
+                  is_torch=True, out_channels=64, baseline="bifpn", num_layers=7, score_thresh=0.5, nms_thres=0.3,
+                  fg_iou_thresh=0.6, bg_iou_thresh=0.5, topk_candidates=1000, detections_per_img=300,
+                  layers=[2, 3, 4, 5])
+    assert isinstance(m, RetinaNet)
+    assert m.nms_thresh == 0.5 and m.score_thresh == 0.5           # nms_thres is swallowed, default kept
+    assert m.detections_per_img == 300 and m.topk_candidates == 1000
+    assert m.proposal_matcher.high_threshold == 0.6 and m.proposal_matcher.low_threshold == 0.5
+    assert m.proposal_matcher.allow_low_quality_matches
+    assert m.head.regression_head._loss_type == "giou"
+    assert len(m.anchor_generator.sizes) == 6 and m.anchor_generator.sizes[0] == (16, 20, 25)
+    p = get_model(4, arch="retinanet", backbone="pyramid_stub", nms_thresh=0.3, score_thresh=0.5, layers=[0, 2, 4, 6])
+    assert p.nms_thresh == 0.3
+    f = get_model(4, arch="fcos", backbone="pyramid_stub", out_channels=32)
+    assert isinstance(f, FCOS) and f.score_thresh == 0.2 and f.nms_thresh == 0.6 and f.detections_per_img == 100
+    with pytest.raises(NotImplementedError):
+        get_model(4, backbone="poolformer_s24")
+    with pytest.raises(RuntimeError):
+        get_model(4, backbone="pyramid_stub", pretrained=True)
+    assert len(anchor_geometry("efficientnetv2_m", [2, 3, 4, 5, 6, 7])[0]) == 6
+    assert len(anchor_geometry("poolformer_s24", [0, 2, 4, 6])[0]) == 6
+    # state-dict keys follow torchvision's layout so the reference's checkpoints ({'weights': state_dict}) load
+    keys = set(m.state_dict().keys())
+    assert "head.classification_head.conv.0.0.weight" in keys and "head.classification_head.conv.0.1.weight" in keys
+    assert "head.regression_head.bbox_reg.bias" in keys and "head.classification_head.cls_logits.weight" in keys
+
+
+def test_head_output_layout_and_train_mode_checks():
+    stub = PyramidStub(3, 32)
+    head = RetinaNetHead(32, 9, 4)
+    feats = list(stub(torch.zeros(2, 3, 64, 64)).values())
+    out = head(feats)
+    n = 9 * (16 * 16 + 8 * 8 + 4 * 4)
+    assert out["cls_logits"].shape == (2, n, 4) and out["bbox_regression"].shape == (2, n, 4)
+    m = get_model(4, backbone="pyramid_stub", layers=[0], out_channels=32)
+    m.train()
+    with pytest.raises(AssertionError):
+        m([torch.zeros(3, 64, 64)], None)
+    with pytest.raises(AssertionError):   # degenerate box
+        m([torch.rand(3, 64, 64)], [{"boxes": torch.tensor([[5., 5., 5., 9.]]), "labels": torch.tensor([1])}])
+
+
+def test_matcher_and_coder_host_behaviour():
+    mt = det_utils.Matcher(0.6, 0.5, True)
+    with pytest.raises(ValueError, match="No ground-truth"):
+        mt(torch.zeros((0, 5)))
+    with pytest.raises(ValueError, match="No proposal"):
+        mt(torch.zeros((3, 0)))
+    with pytest.raises(AssertionError):
+        det_utils.Matcher(0.4, 0.5)
+    # autograd path of BoxCoder.decode_single equals the checker's literal torch restatement
+    coder = det_utils.BoxCoder((1.0, 1.0, 1.0, 1.0))
+    rel = torch.randn(50, 4, requires_grad=True)
+    anchors = torch.rand(50, 4) * 40
+    anchors[:, 2:] += anchors[:, :2] + 1
+    out = coder.decode_single(rel, anchors)
+    assert torch.allclose(out, tv.BoxCoder().decode_single(rel.detach(), anchors, math="torch"))
+    out.sum().backward()
+    assert rel.grad is not None
+    lin = det_utils.BoxLinearCoder(True)
+    assert torch.equal(lin.decode(rel.detach(), anchors), tv.BoxLinearCoder(True).decode(rel.detach(), anchors))
+    assert torch.allclose(lin.encode(anchors, anchors + 1), tv.BoxLinearCoder(True).encode(anchors, anchors + 1))
+    loss = det_utils._box_loss("giou", coder, anchors, anchors + 1.0, rel)
+    assert loss.requires_grad
+    a, b = anchors, anchors + 2
+    assert torch.allclose(det_utils.generalized_box_iou_loss(a, b, "sum"), tv.generalized_box_iou_loss(a, b, "sum"))
+    x, t = torch.randn(10, 3), (torch.rand(10, 3) > 0.5).float()
+    assert torch.allclose(det_utils.sigmoid_focal_loss(x, t, reduction="sum"), tv.sigmoid_focal_loss(x, t, reduction="sum"))
+
+
+def test_transform_resize_and_batch():
+    tr = GeneralizedRCNNTransform(64, 64, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225], nms_thres=0.3)
+    tr.eval()
+    imgs = [torch.rand(3, 100, 80), torch.rand(3, 50, 90)]
+    tg = [{"boxes": torch.tensor([[10., 20., 40., 60.]]), "labels": torch.tensor([1])} for _ in imgs]
+    il, out_t = tr(imgs, tg)
+    assert il.tensors.shape[0] == 2 and il.tensors.shape[-1] % 32 == 0 and il.tensors.shape[-2] % 32 == 0
+    assert il.image_sizes[0] == (64, 51)                         # scale = min(64/80, 64/100) = 0.64
+    assert torch.allclose(out_t[0]["boxes"], torch.tensor([[10 * 51 / 80, 20 * 0.64, 40 * 51 / 80, 60 * 0.64]]))
+    assert torch.equal(tg[0]["boxes"], torch.tensor([[10., 20., 40., 60.]]))   # caller's dict untouched
+    res = tr.postprocess([{"boxes": out_t[0]["boxes"].clone()}], [il.image_sizes[0]], [(100, 80)])
+    assert torch.allclose(res[0]["boxes"], torch.tensor([[10., 20., 40., 60.]]), atol=1e-4)
+
+
+def test_shard_bounds_and_pack():
+    assert [sharding.shard_bounds(16, r, 8) for r in range(8)] == [(2 * r, 2 * r + 2) for r in range(8)]
+    cover = [sharding.shard_bounds(10, r, 4) for r in range(4)]
+    assert cover == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    boxes, scores = torch.rand(2, 5, 4), torch.rand(2, 5)
+    labels = torch.randint(0, 90, (2, 5))
+    packed = sharding.pack_detections(boxes, scores, labels)
+    dets = sharding.unpack_detections(packed, torch.tensor([3, 0]))
+    assert torch.equal(dets[0]["boxes"], boxes[0, :3]) and torch.equal(dets[0]["labels"], labels[0, :3])
+    assert dets[1]["boxes"].shape == (0, 4)
+    g, c = sharding.all_gather_detections(packed, torch.tensor([3, 0]))     # no process group: identity
+    assert g is packed
