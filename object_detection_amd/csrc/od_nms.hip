@@ -6,13 +6,15 @@
 // nms call at object_detection/predict.py:72).
 //
 // Algorithm (greedy NMS is inherently ordered; the work around the order is made parallel):
-//   1. keys (ordered score bits << 32 | ~slot) are bitonic-sorted in LDS: stable descending order.
+//   1. order: unique keys (ordered score bits << 32 | ~slot) give the stable descending order.
+//      Pre-sorted segments (the per-level candidate lists of the pipeline) are merged with a
+//      merge-path tree in LDS (O(n) work per round); arbitrary input is bitonic-sorted in LDS.
 //   2. the sorted boxes are gathered once into an SoA workspace (coordinate-trick offsets applied).
 //   3. candidates are consumed in strips of 256 in sorted order, stopping as soon as max_keep boxes
 //      are kept:
-//        A. every strip candidate is tested against the boxes kept so far (kept boxes are loaded 64
-//           at a time into registers and broadcast lane by lane; 4 thread groups split the kept list);
-//        B. the still-alive candidates are compacted and their pairwise suppression bits
+//        A. every strip candidate is tested against the boxes kept so far (kept boxes live in LDS
+//           and are read as broadcasts; 4 thread groups split the kept list);
+//        B. the still-alive candidates are compacted into LDS and their pairwise suppression bits
 //           (row i suppresses column j, i < j) are computed by all 16 waves into an LDS bit matrix
 //           stored per column;
 //        C. one wave resolves the strip 64 candidates at a time: a column is dead if its bit column
@@ -31,8 +33,28 @@ constexpr int S = 256;                // strip length
 constexpr int PARTS = NT / S;         // thread groups splitting the kept list in phase A
 constexpr int SB = S / 64;            // 64-candidate blocks per strip
 constexpr int MAXN = OD_MAX_NMS_BOXES;
+constexpr int MERGE_MAX = 6144;       // merge-path ordering needs a second key buffer of this many keys
+constexpr int KC = 1024;              // kept boxes cached in LDS (later ones are read from the workspace)
 constexpr int CW = SB * 2 + 1;        // u32 words per column of the bit matrix (+1 pad against bank conflicts)
 constexpr int MAX_SEG = 64;
+
+// LDS carve-up (bytes).  Region B holds the second key buffer while ordering, afterwards the strip state.
+constexpr int OFF_A = 0;                               // u64 keys[MAXN]
+constexpr int OFF_B = OFF_A + MAXN * 8;                // u64 keys2[MERGE_MAX]  |  strip state:
+constexpr int OFF_KBOX = OFF_B;                        //   float4 k_box[KC]
+constexpr int OFF_KAR = OFF_KBOX + KC * 16;            //   float   k_ar[KC]
+constexpr int OFF_KLAB = OFF_KAR + KC * 4;             //   int     k_lab[KC]
+constexpr int OFF_KEPT = OFF_KLAB + KC * 4;            //   u16     kept[MAXN]   (sorted positions)
+constexpr int OFF_ABOX = OFF_KEPT + MAXN * 2;          //   float4  a_box[S]     (alive strip candidates)
+constexpr int OFF_AAR = OFF_ABOX + S * 16;             //   float   a_ar[S]
+constexpr int OFF_ALAB = OFF_AAR + S * 4;              //   int     a_lab[S]
+constexpr int OFF_APOS = OFF_ALAB + S * 4;             //   int     a_pos[S]     (sorted position)
+constexpr int END_B = OFF_APOS + S * 4;
+static_assert(END_B <= OFF_B + MERGE_MAX * 8, "strip state must fit in the second key buffer");
+constexpr int OFF_ORDER = OFF_B + MERGE_MAX * 8;       // u16 order[MAXN]
+constexpr int OFF_COL = OFF_ORDER + MAXN * 2;          // u32 col[S*CW]
+constexpr int OFF_DEAD = OFF_COL + S * CW * 4;         // int dead[S]
+constexpr int LDS_BYTES = OFF_DEAD + S * 4;
 
 struct NmsArgs {
     const float4* boxes;
@@ -52,29 +74,59 @@ struct NmsArgs {
 };
 
 // intersection area exactly as nms_kernel.cpp: max(0, min(x2) - max(x1)) * max(0, min(y2) - max(y1))
-__device__ __forceinline__ float intersection(float ix1, float iy1, float ix2, float iy2, float jx1, float jy1,
-                                              float jx2, float jy2) {
-    const float xx1 = fmaxf(ix1, jx1), yy1 = fmaxf(iy1, jy1);
-    const float xx2 = fminf(ix2, jx2), yy2 = fminf(iy2, jy2);
+__device__ __forceinline__ float intersection(const float4 i, const float4 j) {
+    const float xx1 = fmaxf(i.x, j.x), yy1 = fmaxf(i.y, j.y);
+    const float xx2 = fminf(i.z, j.z), yy2 = fminf(i.w, j.w);
     const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
     return w * h;
 }
 
 // ovr = inter / (iarea + jarea - inter);  (double)ovr > thr  <=>  ovr >= thr_up
-__device__ __forceinline__ bool over_threshold(float inter, float iarea, float jarea, float thr_up) {
+__device__ __forceinline__ bool over_threshold_exact(float inter, float iarea, float jarea, float thr_up) {
     const float ovr = inter / ((iarea + jarea) - inter);
     return ovr >= thr_up;
 }
 
+// Same decision without the IEEE division in the common case: the 1-ulp hardware reciprocal gives
+// ovr to ~4e-7 relative; a value outside the band thr_up*(1 +- 1e-5) decides at once, anything inside
+// it (or NaN / non-positive thresholds, where the band test is not valid) takes the exact division.
+// The branch is wave-uniform so the exact path costs nothing unless some lane needs it.
+struct ThrBand { float up, lo, hi; bool usable; };
+__device__ __forceinline__ bool over_threshold(float inter, float iarea, float jarea, const ThrBand& t) {
+    const float den = (iarea + jarea) - inter;
+    const float approx = inter * __builtin_amdgcn_rcpf(den);
+    const bool above = approx >= t.hi, below = approx <= t.lo;
+    bool res = above;
+    // den below 1e-30 (degenerate boxes): the reciprocal may flush or overflow, decide exactly
+    if (__ballot(!(above || below) || !(den > 1e-30f) || !t.usable) != 0) res = (inter / den) >= t.up;
+    return res;
+}
+
+#ifdef OD_STAMPS
+#define STAMP(k) do { if (threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
-    __shared__ unsigned long long s_keys[MAXN];
-    __shared__ int s_kept[MAXN];
-    __shared__ unsigned int s_col[S * CW];
-    __shared__ int s_dead[S];
-    __shared__ int s_alive[S];
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_BYTES];
     __shared__ int s_segpre[MAX_SEG + 1];
+    __shared__ int s_run[3][MAX_SEG + 1];     // merge rounds: [0] src start, [1] src length, [2] first chunk of pair
     __shared__ int s_tmp[40];
     __shared__ float s_ftmp[NT / 64];
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw + OFF_A);
+    unsigned long long* s_keys2 = reinterpret_cast<unsigned long long*>(s_raw + OFF_B);
+    float4* k_box = reinterpret_cast<float4*>(s_raw + OFF_KBOX);
+    float* k_ar = reinterpret_cast<float*>(s_raw + OFF_KAR);
+    int* k_lab = reinterpret_cast<int*>(s_raw + OFF_KLAB);
+    unsigned short* s_kept = reinterpret_cast<unsigned short*>(s_raw + OFF_KEPT);
+    float4* a_box = reinterpret_cast<float4*>(s_raw + OFF_ABOX);
+    float* a_ar = reinterpret_cast<float*>(s_raw + OFF_AAR);
+    int* a_lab = reinterpret_cast<int*>(s_raw + OFF_ALAB);
+    int* a_pos = reinterpret_cast<int*>(s_raw + OFF_APOS);
+    unsigned short* s_order = reinterpret_cast<unsigned short*>(s_raw + OFF_ORDER);
+    unsigned int* s_col = reinterpret_cast<unsigned int*>(s_raw + OFF_COL);
+    int* s_dead = reinterpret_cast<int*>(s_raw + OFF_DEAD);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -90,6 +142,11 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     float* sar = sy2 + a.n_pad;
     int* slab = reinterpret_cast<int*>(sar + a.n_pad);
     int* sslot = slab + a.n_pad;
+#ifdef OD_STAMPS
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.ws + (long long)gridDim.x * 7 * a.n_pad) + blockIdx.x * 32;
+    int stamp_i = 4;
+#endif
+    STAMP(0);
 
     // ---- 1. keys, valid count, max coordinate ------------------------------------------------------
     if (tid == 0) {
@@ -130,26 +187,109 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     if (mode == OD_NMS_AUTO_GPU) mode = (4 * n_valid > 20000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
     const bool vanilla = (mode == OD_NMS_VANILLA) && labels != nullptr;
     const bool trick = (mode == OD_NMS_TRICK) && labels != nullptr;
+    STAMP(1);
 
-    // ---- 2. bitonic sort (descending): (score desc, slot asc) --------------------------------------
-    for (int k = 2; k <= a.n_pad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < a.n_pad; i += NT) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long x = s_keys[i], y = s_keys[ixj];
-                    const bool desc = (i & k) == 0;
-                    if ((x < y) == desc) { s_keys[i] = y; s_keys[ixj] = x; }
+    // ---- 2. order: s_order[rank] = slot, ranks by (score desc, slot asc) --------------------------
+    if (a.segments_sorted && a.n_slots <= MERGE_MAX) {
+        // merge-path tree over the pre-sorted segments: each round merges adjacent runs pairwise
+        unsigned long long* src = s_keys;
+        unsigned long long* dst = s_keys2;
+        int nruns = a.num_seg;
+        if (tid < nruns) { s_run[0][tid] = tid * a.seg_stride; s_run[1][tid] = s_segpre[tid + 1] - s_segpre[tid]; }
+        __syncthreads();
+        const int CH = (n_valid + NT - 1) / NT > 0 ? (n_valid + NT - 1) / NT : 1;   // outputs per chunk
+        while (nruns > 1) {
+            const int npairs = (nruns + 1) >> 1;
+            if (tid == 0) {
+                int chunk = 0;
+                for (int p = 0; p < npairs; ++p) {
+                    const int la = s_run[1][2 * p];
+                    const int lb = (2 * p + 1 < nruns) ? s_run[1][2 * p + 1] : 0;
+                    s_run[2][p] = chunk;
+                    chunk += (la + lb + CH - 1) / CH;
+                }
+                s_run[2][npairs] = chunk;
+            }
+            __syncthreads();
+            const int nchunks = s_run[2][npairs];
+            for (int ch = tid; ch < nchunks; ch += NT) {
+                int p = 0;
+                while (p + 1 < npairs && ch >= s_run[2][p + 1]) ++p;
+                const int sa = s_run[0][2 * p], na = s_run[1][2 * p];
+                const bool hasb = 2 * p + 1 < nruns;
+                const int sb = hasb ? s_run[0][2 * p + 1] : 0, nb = hasb ? s_run[1][2 * p + 1] : 0;
+                int outbase = 0;
+                for (int q = 0; q < p; ++q)
+                    outbase += s_run[1][2 * q] + ((2 * q + 1 < nruns) ? s_run[1][2 * q + 1] : 0);
+                const int k0 = (ch - s_run[2][p]) * CH;
+                const int k1 = (k0 + CH < na + nb) ? k0 + CH : na + nb;
+                // co-rank: i = number of A elements among the first k0 outputs
+                int lo = k0 - nb > 0 ? k0 - nb : 0, hi = k0 < na ? k0 : na;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (src[sa + mid] > src[sb + (k0 - mid - 1)]) lo = mid + 1; else hi = mid;
+                }
+                int i = lo, j = k0 - lo;
+                for (int k = k0; k < k1; ++k) {
+                    const unsigned long long va = (i < na) ? src[sa + i] : 0ull;
+                    const unsigned long long vb = (j < nb) ? src[sb + j] : 0ull;
+                    const bool takea = (j >= nb) || (i < na && va > vb);
+                    dst[outbase + k] = takea ? va : vb;
+                    i += takea ? 1 : 0;
+                    j += takea ? 0 : 1;
                 }
             }
             __syncthreads();
+            if (tid == 0) {
+                int acc = 0;
+                for (int p = 0; p < npairs; ++p) {
+                    const int len = s_run[1][2 * p] + ((2 * p + 1 < nruns) ? s_run[1][2 * p + 1] : 0);
+                    s_run[0][p] = acc;
+                    s_run[1][p] = len;
+                    acc += len;
+                }
+            }
+            __syncthreads();
+            nruns = npairs;
+            unsigned long long* t = src; src = dst; dst = t;
         }
+        const int start = s_run[0][0];
+        for (int p = tid; p < n_valid; p += NT) s_order[p] = (unsigned short)(0xFFFFFFFFu - (uint32_t)src[start + p]);
+        __syncthreads();
+    } else {
+        // bitonic sort of the keys, descending; each thread owns n_pad/2/NT disjoint pairs per stage,
+        // loads them all, then stores (the LDS latency is paid once per stage, not once per pair)
+        constexpr int PQ = MAXN / 2 / NT;
+        for (int k = 2; k <= a.n_pad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long x[PQ], y[PQ];
+                int lo[PQ];
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    const int pr = tid + q * NT;                          // pair index
+                    lo[q] = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));      // insert a 0 bit at log2(j)
+                    const bool on = pr < (a.n_pad >> 1);
+                    x[q] = on ? s_keys[lo[q]] : 0ull;
+                    y[q] = on ? s_keys[lo[q] | j] : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < PQ; ++q) {
+                    const int pr = tid + q * NT;
+                    const bool desc = (lo[q] & k) == 0;
+                    if (pr < (a.n_pad >> 1) && ((x[q] < y[q]) == desc)) { s_keys[lo[q]] = y[q]; s_keys[lo[q] | j] = x[q]; }
+                }
+                __syncthreads();
+            }
+        }
+        for (int p = tid; p < n_valid; p += NT) s_order[p] = (unsigned short)(0xFFFFFFFFu - (uint32_t)s_keys[p]);
+        __syncthreads();
     }
+    STAMP(2);
 
     // ---- 3. gather sorted boxes into the SoA workspace --------------------------------------------
     const float step = maxc + 1.0f;   // offsets = labels.to(boxes) * (boxes.max() + 1)
     for (int p = tid; p < n_valid; p += NT) {
-        const int slot = (int)(0xFFFFFFFFu - (uint32_t)s_keys[p]);
+        const int slot = (int)s_order[p];
         float4 bx = boxes[slot];
         const int lab = labels ? labels[slot] : 0;
         if (trick) {
@@ -163,55 +303,85 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     }
     if (tid == 0) { s_tmp[0] = 0; s_tmp[1] = 0; }   // [0] = kept count, [1] = done flag
     __syncthreads();
+    STAMP(3);
 
     const int max_keep = a.max_keep < n_valid ? a.max_keep : n_valid;
-    const float thr_up = a.thr_up;
+    ThrBand thr;
+    thr.up = a.thr_up;
+    thr.lo = a.thr_up * (1.0f - 1e-5f);
+    thr.hi = a.thr_up * (1.0f + 1e-5f);
+    thr.usable = (a.thr_up > 1e-30f) && (a.thr_up < 1e30f);
     const bool can_skip = a.can_skip_zero != 0;
 
     // ---- 4. strips ------------------------------------------------------------------------------------
-    for (int s0 = 0; s0 < n_valid && max_keep > 0; s0 += S) {
+    for (int s0 = 0, SL = S; s0 < n_valid && max_keep > 0; s0 += SL) {
         const int nk = s_tmp[0];
+        // strip length: the full 256 while many boxes are still wanted, shorter (a multiple of 64) once
+        // only a few are missing (64 or 128), so that the last strip does not test 256 candidates to keep a handful
+        {
+            const int want = max_keep - nk;
+            const int target = want + (want >> 1);
+            SL = target <= 64 ? 64 : (target <= 128 ? 128 : S);      // power of two: c = tid & (SL - 1)
+        }
+        const int parts = NT / SL;
         if (tid < S) s_dead[tid] = 0;
         for (int i = tid; i < S * CW; i += NT) s_col[i] = 0u;
         __syncthreads();
 
         // -- A: against the kept list ------------------------------------------------------------------
+        const int c = tid & (SL - 1);
+        const int part = tid / SL;
+        const int p = s0 + c;
+        const bool valid = p < n_valid;
+        const int pp = valid ? p : n_valid - 1;
+        const float4 jb = make_float4(sx1[pp], sy1[pp], sx2[pp], sy2[pp]);
+        const float jar = sar[pp];
+        const int jlab = slab[pp];
         {
-            const int c = tid & (S - 1);
-            const int part = tid / S;
-            const int p = s0 + c;
-            const bool valid = p < n_valid;
-            const int pp = valid ? p : n_valid - 1;
-            const float jx1 = sx1[pp], jy1 = sy1[pp], jx2 = sx2[pp], jy2 = sy2[pp], jar = sar[pp];
-            const int jlab = slab[pp];
             bool dead = false;
-            for (int kb = part; kb * 64 < nk; kb += PARTS) {
-                const int e = kb * 64 + lane;
-                const int kp = s_kept[e < nk ? e : nk - 1];
-                const float kx1 = sx1[kp], ky1 = sy1[kp], kx2 = sx2[kp], ky2 = sy2[kp], kar = sar[kp];
-                const int klab = slab[kp];
-                const int cnt = (nk - kb * 64) < 64 ? (nk - kb * 64) : 64;
-                for (int i = 0; i < cnt; ++i) {
-                    const float ix1 = bcast_lane(kx1, i), iy1 = bcast_lane(ky1, i);
-                    const float ix2 = bcast_lane(kx2, i), iy2 = bcast_lane(ky2, i);
-                    const float iar = bcast_lane(kar, i);
-                    const float inter = intersection(ix1, iy1, ix2, iy2, jx1, jy1, jx2, jy2);
-                    if (can_skip && __ballot(inter > 0.0f) == 0) continue;
-                    bool sup = over_threshold(inter, iar, jar, thr_up);
-                    if (vanilla) sup = sup && (bcast_lane(klab, i) == jlab);
+            const int nk_lds = nk < KC ? nk : KC;
+            for (int e0 = part * 4; e0 < nk_lds; e0 += parts * 4) {
+                float inter[4], iar[4];
+                bool anypos = false;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = (e0 + u < nk_lds) ? e0 + u : nk_lds - 1;     // tail repeats the last kept box
+                    inter[u] = intersection(k_box[e], jb);
+                    iar[u] = k_ar[e];
+                    anypos = anypos || (inter[u] > 0.0f);
+                }
+                if (can_skip && __ballot(anypos) == 0) continue;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = (e0 + u < nk_lds) ? e0 + u : nk_lds - 1;
+                    bool sup = over_threshold(inter[u], iar[u], jar, thr);
+                    if (vanilla) sup = sup && (k_lab[e] == jlab);
                     dead = dead || sup;
                 }
+            }
+            for (int e = KC + part; e < nk; e += parts) {      // kept boxes beyond the LDS cache
+                const int kp = s_kept[e];
+                const float4 kb = make_float4(sx1[kp], sy1[kp], sx2[kp], sy2[kp]);
+                const float inter = intersection(kb, jb);
+                bool sup = over_threshold_exact(inter, sar[kp], jar, thr.up);
+                if (vanilla) sup = sup && (slab[kp] == jlab);
+                dead = dead || sup;
             }
             if (dead && valid) s_dead[c] = 1;
         }
         __syncthreads();
+#ifdef OD_STAMPS
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
 
-        // -- compact the alive candidates of the strip (order preserved) -----------------------------
-        if (tid < S) {
-            const bool alive = (s0 + tid < n_valid) && (s_dead[tid] == 0);
+        // -- compact the alive candidates of the strip into LDS (order preserved) ---------------------
+        bool alive = false;
+        int wrank = 0;
+        if (tid < SL) {
+            alive = valid && (s_dead[tid] == 0);
             const uint64_t bal = __ballot(alive);
             if (lane == 0) s_tmp[8 + wave] = __popcll(bal);
-            s_dead[tid] = alive ? mbcnt(bal) : -1;   // reuse: rank inside the wave, or -1
+            wrank = mbcnt(bal);
         }
         __syncthreads();
         int na = 0;
@@ -219,14 +389,20 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
             int pre = 0;
 #pragma unroll
             for (int w = 0; w < SB; ++w) {
-                const int c = s_tmp[8 + w];
-                if (w < wave) pre += c;
-                na += c;
+                const int cw = (w * 64 < SL) ? s_tmp[8 + w] : 0;
+                if (w < wave) pre += cw;
+                na += cw;
             }
-            if (tid < S && s_dead[tid] >= 0) s_alive[pre + s_dead[tid]] = tid;
+            if (alive) {
+                const int q = pre + wrank;
+                a_box[q] = jb; a_ar[q] = jar; a_lab[q] = jlab; a_pos[q] = p;
+            }
         }
         __syncthreads();
         const int nab = (na + 63) >> 6;
+#ifdef OD_STAMPS
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
 
         // -- B: pairwise bits among alive candidates, 16 rows x 64 columns per work item --------------
         {
@@ -238,31 +414,41 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
                 const int cb = rb + t;
                 const int col = cb * 64 + lane;
                 const bool cvalid = col < na;
-                const int cp = s0 + s_alive[cvalid ? col : na - 1];
-                const float jx1 = sx1[cp], jy1 = sy1[cp], jx2 = sx2[cp], jy2 = sy2[cp], jar = sar[cp];
-                const int jlab = slab[cp];
+                const int cq = cvalid ? col : na - 1;
+                const float4 cbx = a_box[cq];
+                const float car = a_ar[cq];
+                const int clab = a_lab[cq];
                 const int row0 = rb * 64 + quarter * 16;
-                const int rrow = row0 + (lane & 15);
-                const int rp = s0 + s_alive[rrow < na ? rrow : na - 1];
-                const float rx1 = sx1[rp], ry1 = sy1[rp], rx2 = sx2[rp], ry2 = sy2[rp], rar = sar[rp];
-                const int rlab = slab[rp];
                 const int rcnt = (na - row0) < 16 ? (na - row0) : 16;
                 unsigned int bits = 0u;
-                for (int i = 0; i < rcnt; ++i) {
-                    const float ix1 = bcast_lane(rx1, i), iy1 = bcast_lane(ry1, i);
-                    const float ix2 = bcast_lane(rx2, i), iy2 = bcast_lane(ry2, i);
-                    const float iar = bcast_lane(rar, i);
-                    const float inter = intersection(ix1, iy1, ix2, iy2, jx1, jy1, jx2, jy2);
-                    if (can_skip && __ballot(inter > 0.0f) == 0) continue;
-                    bool sup = over_threshold(inter, iar, jar, thr_up);
-                    if (vanilla) sup = sup && (bcast_lane(rlab, i) == jlab);
-                    sup = sup && (row0 + i < col);
-                    bits |= sup ? (1u << i) : 0u;
+                for (int i0 = 0; i0 < rcnt; i0 += 4) {
+                    float inter[4], iar[4];
+                    bool anypos = false;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = (row0 + i0 + u < na) ? row0 + i0 + u : na - 1;   // masked below
+                        inter[u] = intersection(a_box[r], cbx);
+                        iar[u] = a_ar[r];
+                        anypos = anypos || (inter[u] > 0.0f);
+                    }
+                    if (can_skip && __ballot(anypos) == 0) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + u;
+                        const int r = (row0 + i < na) ? row0 + i : na - 1;
+                        bool sup = over_threshold(inter[u], iar[u], car, thr);
+                        if (vanilla) sup = sup && (a_lab[r] == clab);
+                        sup = sup && (i < rcnt) && (row0 + i < col);
+                        bits |= sup ? (1u << i) : 0u;
+                    }
                 }
                 if (cvalid && bits) atomicOr(&s_col[col * CW + rb * 2 + (quarter >> 1)], bits << ((quarter & 1) * 16));
             }
         }
         __syncthreads();
+#ifdef OD_STAMPS
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
 
         // -- C: resolve the strip in order (one wave) ---------------------------------------------------
         if (wave == 0) {
@@ -279,10 +465,10 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
                     const unsigned int* cw = &s_col[(cvalid ? col : 0) * CW];
                     bool dead = false;
 #pragma unroll
-                    for (int c = 0; c < SB; ++c) {
-                        if (c < blk) {
-                            const unsigned long long m = ((unsigned long long)cw[2 * c + 1] << 32) | cw[2 * c];
-                            dead = dead || ((m & keptw[c]) != 0ull);
+                    for (int cc = 0; cc < SB; ++cc) {
+                        if (cc < blk) {
+                            const unsigned long long m = ((unsigned long long)cw[2 * cc + 1] << 32) | cw[2 * cc];
+                            dead = dead || ((m & keptw[cc]) != 0ull);
                         }
                     }
                     const unsigned long long own = ((unsigned long long)cw[2 * blk + 1] << 32) | cw[2 * blk];
@@ -296,7 +482,10 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
                     keptw[blk] = K;
                     const bool kept = (K >> lane) & 1ull;
                     const int pos = nkept + mbcnt(K);
-                    if (kept && pos < max_keep) s_kept[pos] = s0 + s_alive[col];
+                    if (kept && pos < max_keep) {
+                        s_kept[pos] = (unsigned short)a_pos[col];
+                        if (pos < KC) { k_box[pos] = a_box[col]; k_ar[pos] = a_ar[col]; k_lab[pos] = a_lab[col]; }
+                    }
                     nkept += __popcll(K);
                     if (nkept >= max_keep) { nkept = max_keep; done = true; }
                 }
@@ -304,9 +493,13 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
             if (lane == 0) { s_tmp[0] = nkept; s_tmp[1] = done ? 1 : 0; }
         }
         __syncthreads();
+#ifdef OD_STAMPS
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
         if (s_tmp[1]) break;
     }
     __syncthreads();
+    STAMP(30);
 
     // ---- 5. outputs -----------------------------------------------------------------------------------
     const int nk = s_tmp[0];
@@ -329,6 +522,7 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
         }
     }
     if (tid == 0) a.out_count[b] = nk;
+    STAMP(31);
 }
 
 int next_pow2(int v) {
@@ -343,7 +537,7 @@ extern "C" size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg,
     if (batch < 0 || num_seg < 1 || seg_stride < 1) return 0;
     long long n = (long long)num_seg * seg_stride;
     if (n > MAXN) return 0;
-    size_t b = (size_t)batch * 7 * (size_t)next_pow2((int)n) * 4;
+    size_t b = (size_t)batch * 7 * (size_t)next_pow2((int)n) * 4 + (size_t)batch * 256;   // + debug stamps
     return (b + 255) & ~(size_t)255;
 }
 

@@ -1,0 +1,84 @@
+"""Per-kernel timings on the GPU (HIP events inside the library) for quick A/B while tuning."""
+import argparse
+import dataclasses
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from object_detection_amd import _C, kernels, synthetic  # noqa: E402
+from object_detection_amd.retinanet import _image_hw_tensor  # noqa: E402
+from oracle import tv_reference as tv  # noqa: E402
+
+
+def timed(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    _C.profile_select(_C.PROFILE_ALL)
+    for k in range(len(_C.KERNEL_NAMES)):
+        _C.profile_read(k)
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    out = {}
+    for k, name in enumerate(_C.KERNEL_NAMES):
+        ms, n = _C.profile_read(k)
+        if n:
+            out[name] = round(1e3 * ms / n, 2)
+    _C.profile_select(_C.PROFILE_OFF)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--what", default="all")
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--gt", type=int, default=100)
+    args = ap.parse_args()
+    dev = torch.device("cuda:0")
+    cfg = dataclasses.replace(synthetic.CFG2, batch=args.batch, num_gt=args.gt)
+    sizes = synthetic.level_sizes(cfg)
+    ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
+    grids = [(g, g) for g in cfg.grids]
+    strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
+    anchors = kernels.anchor_generate(grids, strides, ag.cell_anchors, dev)
+    res = {}
+    if args.what in ("all", "match"):
+        targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)
+        gts = [t["boxes"].to(dev) for t in targets]
+        res["match"] = timed(lambda: kernels.match_retinanet(anchors, gts, 0.6, 0.5, True))
+    if args.what in ("all", "post", "nms", "select"):
+        head = synthetic.make_head_outputs(cfg)
+        cls = head["cls_logits"].to(dev)
+        reg = head["bbox_regression"].to(dev)
+        cls_l, reg_l, anc_l = list(cls.split(sizes, 1)), list(reg.split(sizes, 1)), list(anchors.split(sizes))
+        hw = _image_hw_tensor([cfg.image_size] * cfg.batch, dev)
+        K = cfg.topk_candidates
+        sel = lambda: kernels.select_candidates(cls_l, reg_l, anc_l, hw, cfg.score_thresh, K, _C.CODER_BOXCODER, 4.135)
+        res["select"] = timed(sel)
+        cb, cs, cl, _, cc = sel()
+        res["cand_per_image"] = float(cc.sum().item()) / cfg.batch
+        for mk in (1, 100, 500, 6000):
+            res[f"nms_keep{mk}"] = timed(lambda: kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh,
+                                                                           _C.NMS_AUTO_GPU, mk, want_keep_idx=False))
+        for thr in (0.05, 0.9):
+            res[f"nms_thr{thr}_keep500"] = timed(lambda: kernels.batched_nms_padded(cb, cs, cl, cc, K, True, thr,
+                                                                                   _C.NMS_AUTO_GPU, 500, want_keep_idx=False))
+    if os.environ.get("OD_STAMPS"):
+        kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh, _C.NMS_AUTO_GPU, 500, want_keep_idx=False)
+        torch.cuda.synchronize()
+        ws = kernels._workspaces[(dev.index, "nms")]
+        off = cfg.batch * 7 * 8192 * 4
+        st = ws[off:off + cfg.batch * 256].view(torch.int64).view(cfg.batch, 32).cpu()
+        for b in (0, 5):
+            r = st[b]
+            res[f"stamps_us_img{b}"] = [round(float(r[i] - r[0]) / 100.0, 1) for i in list(range(0, 4)) + list(range(4, 20)) + [30, 31]]
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
