@@ -42,8 +42,8 @@ def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
     return {
         "filter": 4.0 * B * N * C,                       # every logit read once
         "select": 12.0 * B * L * K + 48.0 * B * L * K,   # candidate keys + (reg, anchor, box out)
-        "match_gtmax": B * (16.0 * N + 16.0 * M),        # anchors + GT read
-        "match_assign": B * (16.0 * N + 16.0 * M + 8.0 * N),   # + int64 matched index written
+        "match_assign": B * (16.0 * N + 16.0 * M + 8.0 * N),   # anchors + GT read, int64 matched index written
+        "match_restore": 0.0,                            # patches a few anchors; no mandatory traffic
         "nms": B * (28.0 * n_cand_per_image + 8.0 * D),
         "anchor": 16.0 * N,
     }.get(kernel, 0.0)

@@ -69,7 +69,7 @@ int od_anchor_generate(const int32_t* grid_h, const int32_t* grid_w, const int32
  *   matched             : int64 [batch, n]: matched GT index, -1 below `low`, -2 between thresholds;
  *                         an image with zero GT boxes gets all -1 (compute_loss's empty-target guard)
  */
-size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch);
+size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch, int64_t n);
 int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n, const float* gt_boxes,
                        const int32_t* gt_offsets, int64_t m_total, int32_t batch, float high, float low,
                        int32_t allow_low_quality, int64_t* matched, void* workspace, size_t workspace_bytes,
@@ -168,8 +168,8 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
 #define OD_PROFILE_OFF (-1)
 #define OD_PROFILE_ALL (-2)
 #define OD_KERNEL_ANCHOR 0
-#define OD_KERNEL_MATCH_GTMAX 1     /* od_match_retinanet pass 1: per-GT maxima          */
-#define OD_KERNEL_MATCH_ASSIGN 2    /* od_match_retinanet pass 2: argmax/threshold/restore */
+#define OD_KERNEL_MATCH_ASSIGN 1    /* od_match_retinanet: argmax / thresholds / per-GT maxima */
+#define OD_KERNEL_MATCH_RESTORE 2   /* od_match_retinanet: low-quality-match restore from entries */
 #define OD_KERNEL_MATCH_FCOS 3
 #define OD_KERNEL_BOX_IOU 4
 #define OD_KERNEL_MATCHER 5         /* both kernels of od_matcher */
@@ -177,7 +177,9 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
 #define OD_KERNEL_FILTER 7          /* od_select_candidates: score filter stream          */
 #define OD_KERNEL_SELECT 8          /* od_select_candidates: top-k + decode + clip        */
 #define OD_KERNEL_NMS 9
-#define OD_KERNEL_COUNT 10
+#define OD_KERNEL_MATCH_HEAVY 10     /* od_match_retinanet: cooperative kernel for GT-heavy tiles */
+#define OD_KERNEL_MATCH_FLAG 11
+#define OD_KERNEL_COUNT 12
 int od_profile_select(int32_t kernel_id);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 

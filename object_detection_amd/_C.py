@@ -32,7 +32,7 @@ _P = c_void_p
 SIGNATURES = {
     "od_version": (c_int32, []),
     "od_anchor_generate": (c_int32, [_P, _P, _P, _P, _P, _P, c_int32, _P, c_int64, _P]),
-    "od_match_retinanet_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "od_match_retinanet_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int64]),
     "od_match_retinanet": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_float, c_float, c_int32,
                                      _P, _P, c_size_t, _P]),
     "od_match_fcos": (c_int32, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int32, c_float, _P, _P]),
@@ -51,8 +51,8 @@ SIGNATURES = {
 }
 
 PROFILE_OFF, PROFILE_ALL = -1, -2
-KERNEL_NAMES = ["anchor", "match_gtmax", "match_assign", "match_fcos", "box_iou", "matcher", "decode", "filter",
-                "select", "nms"]
+KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
+                "select", "nms", "match_heavy", "match_flag"]
 
 _lib = None
 

@@ -139,10 +139,24 @@ __device__ __forceinline__ float spec_sigmoidf(float x) {
 
 // ---- IoU exactly as torchvision.ops.boxes.box_iou computes one (gt, anchor) entry -------------
 // inter = clamp(min(x2)-max(x1),0) * clamp(min(y2)-max(y1),0); union = (area_gt + area_a) - inter
+// v_min_f32 / v_max_f32 issued directly.  fminf()/fmaxf() make the compiler quiet a possible signalling NaN
+// of every operand it cannot trace to an arithmetic result (one extra v_max per operand and use, even for
+// loop-invariant registers); for non-NaN inputs the bare instructions return the same value.
+__device__ __forceinline__ float hw_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float hw_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ float iou_pair(float gx1, float gy1, float gx2, float gy2, float garea,
                                           float ax1, float ay1, float ax2, float ay2, float aarea) {
-    float w = fmaxf(fminf(gx2, ax2) - fmaxf(gx1, ax1), 0.0f);
-    float h = fmaxf(fminf(gy2, ay2) - fmaxf(gy1, ay1), 0.0f);
+    float w = fmaxf(hw_min(gx2, ax2) - hw_max(gx1, ax1), 0.0f);
+    float h = fmaxf(hw_min(gy2, ay2) - hw_max(gy1, ay1), 0.0f);
     float inter = w * h;
     float uni = (garea + aarea) - inter;
     return inter / uni;

@@ -4,18 +4,29 @@
 // (the per-image loop body of RetinaNet.compute_loss; reference trigger object_detection/train.py:62,
 // thresholds object_detection/configs/config_all.py:10-11).  The [M,N] IoU matrix is never stored.
 //
-// Work decomposition: one workgroup = one tile of 1024 consecutive anchors of one image
-// (256 threads x 4 anchors, anchors live in registers).  GT boxes are staged through LDS in chunks;
-// a GT whose box cannot overlap the tile's bounding box is culled (its IoU with every anchor of the
-// tile is exactly +0, which can neither win a strict '>' argmax nor raise a per-GT maximum), and the
-// survivors keep their ascending order so "first maximal index" tie-breaking is unchanged.
+// The kernels are VALU-issue bound (a non-packed fp32 VALU instruction occupies a SIMD for 4 cycles on
+// gfx950), so the design minimises instructions per (anchor, GT) pair, not bytes:
+//   * work unit = one WAVE owning 256 consecutive anchors (4 per lane, in registers).  The wave keeps
+//     the bounding box of its anchors and skips every GT that cannot overlap it: such a GT has IoU
+//     exactly +0 with all 256 anchors, which can neither win a strict '>' argmax nor raise a per-GT
+//     maximum.  Small units make tight boxes: ~2 % of the GT survive on the finest pyramid level.
+//   * GT boxes are read 64 at a time (one per lane), the survivors are visited in ascending order
+//     through a ballot mask and broadcast with v_readlane: no LDS, no barriers, scalar loop control,
+//     and "first maximal index" tie-breaking is unchanged.
+//   * a wave tile that meets more than HEAVY GT (coarse pyramid levels) would be a long serial loop on
+//     the critical path; it is queued and processed by 16 cooperating waves instead (heavy kernel).
 //
-// Two passes over the same code path (so recomputed IoUs are bit-identical):
-//   pass 1: per-GT maximum over all anchors  (wave DPP max -> LDS atomic max -> global atomic max)
-//   pass 2: per-anchor max/argmax, thresholds, and the low-quality restore
-//           (anchor a is restored to its own argmax when iou[g,a] == max_a' iou[g,a'] for some g).
-// If some GT has maximum 0 (it overlaps no anchor) torchvision restores EVERY anchor (all of them tie
-// at 0 for that GT); pass 2 detects that case from the per-GT maxima and does the same.
+// assign / heavy kernels: per-anchor max / argmax / thresholds -> `matched`, the raw argmax -> workspace,
+//   per-GT maximum over the wave's anchors (DPP max) -> global atomic max, and one 8-byte entry per
+//   (tile, GT with positive IoU): the GT, the tile's maximum, the first anchor attaining it and a flag
+//   telling whether other anchors of the tile tie with it.
+// restore kernel (only with allow_low_quality_matches): torchvision restores anchor a to its own argmax
+//   when iou[g,a] equals the maximum of row g.  Such an anchor attains its tile's maximum, so the kernel
+//   only compares each entry's value with the global maximum of its GT and patches `matched` from the
+//   stored argmax.  For an entry flagged as a tie the wave recomputes that one
+//   (tile, GT) row segment with the same IoU code (hence bit-identical values) to find all tied anchors.
+//   If some GT has maximum 0 (it overlaps no anchor) every anchor ties at 0 for that row and torchvision
+//   restores ALL anchors; a flag per image reproduces that.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -23,170 +34,464 @@ namespace {
 
 using namespace od;
 
-constexpr int MT = 256;        // threads per workgroup
-constexpr int R = 4;           // anchors per thread
-constexpr int TILE = MT * R;   // anchors per workgroup
-constexpr int GCH = 512;       // GT boxes staged per chunk (2 per thread)
+constexpr int MT = 256;          // threads per workgroup = 4 independent waves
+constexpr int R = 4;             // anchors per lane
+constexpr int WTILE = 64 * R;    // anchors per wave
+constexpr int HEAVY = 24;        // a wave tile meeting more GT than this goes to the cooperative kernel
+constexpr int LCAP = HEAVY;      // entries of a light wave tile: one per GT with positive IoU
+#ifndef OD_HT
+#define OD_HT 256
+#endif
+constexpr int HT = OD_HT;        // threads of the cooperative (heavy tile) workgroup
+constexpr int HCAP_PER_GT = 160;  // heavy-entry buffer capacity = HCAP_PER_GT * m_total + 4096
 
-struct GtAux {                 // second 16-byte LDS record per staged GT
-    float area;
-    float gmax;                // pass 2: global maximum IoU of this GT
-    int index;                 // GT index inside its image
-    int pad;
+struct MatchWs {                 // workspace carve-up (all device pointers)
+    uint32_t* gt_max_key;        // [m_total]          ordered-key maximum IoU of every GT row
+    int* argmax;                 // [batch, n]         per-anchor argmax before thresholding
+    int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
+    uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT << 9 | several << 8 | local anchor, y = value key
+    int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
+    unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
+    int* any_flag;               // [1]                some image_flag is set
+    int2* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot) for the cooperative kernel
+    uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = entry word, z = value key; image b owns the
+                                 //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
+    unsigned long long* wave_mask;   // [LCAP * batch * wtiles][R]  attaining-anchor masks of tie entries (same index as wave_list)
+    unsigned long long* heavy_mask;  // [heavy_cap][R]     same for heavy_entries
+    long long list_stride;       // batch * wtiles
 };
 
-template <int PASS>
-__global__ __launch_bounds__(MT) void match_retinanet_kernel(
-    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n,
-    const float4* __restrict__ gt, const int* __restrict__ gt_offsets, uint32_t* gt_max_key,
-    float high, float low, int allow_lq, long long* __restrict__ matched) {
-    __shared__ float4 s_g[GCH];
-    __shared__ GtAux s_aux[GCH];
-    __shared__ uint32_t s_tilemax[GCH];
-    __shared__ float s_red[4][4];
-    __shared__ float s_bbox[4];
-    __shared__ int s_wcnt[4];
-    __shared__ int s_flag;
+constexpr uint32_t kZeroKey = 0x80000000u;           // ordered_key(+0.0f), the initial per-GT maximum
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int b = blockIdx.y;
-    const long long tile_base = (long long)blockIdx.x * TILE;
-    const int m0 = gt_offsets[b];
-    const int M = gt_offsets[b + 1] - m0;
-    long long* out = matched + (long long)b * n;
+// heavy-entry slots of an image: proportional to its own GT count, so that images cannot starve each other
+__device__ __forceinline__ long long entry_base(int b, int m0) { return (long long)HCAP_PER_GT * m0 + 256ll * b; }
+__device__ __forceinline__ long long entry_cap(int M) { return (long long)HCAP_PER_GT * M + 256; }
 
-    if (M <= 0) {                                   // empty-target guard of compute_loss
-        if (PASS == 2) {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                long long idx = tile_base + tid + r * MT;
-                if (idx < n) out[idx] = -1;
-            }
-        }
-        return;
-    }
-
-    // ---- anchors of this tile into registers (out-of-range lanes replay the last anchor) --------
-    const float4* A = anchors + (long long)b * anchor_batch_stride;
+struct WaveTile {
     float ax1[R], ay1[R], ax2[R], ay2[R], aarea[R];
+    float bx1, by1, bx2, by2;    // bounding box of the wave's anchors (wave-uniform)
+};
+
+__device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __restrict__ A, long long base, long long n) {
+    const int lane = threadIdx.x & 63;
     float bx1 = __builtin_inff(), by1 = __builtin_inff(), bx2 = -__builtin_inff(), by2 = -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        long long idx = tile_base + tid + r * MT;
-        if (idx > n - 1) idx = n - 1;
-        float4 a = A[idx];
-        ax1[r] = a.x; ay1[r] = a.y; ax2[r] = a.z; ay2[r] = a.w;
-        aarea[r] = box_area(a.x, a.y, a.z, a.w);
+        long long idx = base + r * 64 + lane;
+        if (idx > n - 1) idx = n - 1;               // out-of-range lanes replay the last anchor
+        const float4 a = A[idx];
+        t.ax1[r] = a.x; t.ay1[r] = a.y; t.ax2[r] = a.z; t.ay2[r] = a.w;
+        t.aarea[r] = box_area(t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r]);
         bx1 = fminf(bx1, a.x); by1 = fminf(by1, a.y);
         bx2 = fmaxf(bx2, a.z); by2 = fmaxf(by2, a.w);
     }
-    // tile bounding box: wave DPP reductions, then across the 4 waves through LDS
-    bx1 = wave_fmin_all(bx1); by1 = wave_fmin_all(by1);
-    bx2 = wave_fmax_all(bx2); by2 = wave_fmax_all(by2);
-    if (lane == 0) { s_red[wave][0] = bx1; s_red[wave][1] = by1; s_red[wave][2] = bx2; s_red[wave][3] = by2; }
-    if (tid == 0) s_flag = 0;
-    __syncthreads();
-    if (tid == 0) {
-        s_bbox[0] = fminf(fminf(s_red[0][0], s_red[1][0]), fminf(s_red[2][0], s_red[3][0]));
-        s_bbox[1] = fminf(fminf(s_red[0][1], s_red[1][1]), fminf(s_red[2][1], s_red[3][1]));
-        s_bbox[2] = fmaxf(fmaxf(s_red[0][2], s_red[1][2]), fmaxf(s_red[2][2], s_red[3][2]));
-        s_bbox[3] = fmaxf(fmaxf(s_red[0][3], s_red[1][3]), fmaxf(s_red[2][3], s_red[3][3]));
-    }
-    // pass 2: does some GT of this image have maximum IoU == 0 ?  (then every anchor is restored)
-    if (PASS == 2 && allow_lq) {
-        int any0 = 0;
-        for (int g = tid; g < M; g += MT) any0 |= (ordered_key_inv(gt_max_key[m0 + g]) == 0.0f);
-        if (any0) s_flag = 1;   // benign race: every writer stores 1
-    }
-    __syncthreads();
-    const float tb_x1 = s_bbox[0], tb_y1 = s_bbox[1], tb_x2 = s_bbox[2], tb_y2 = s_bbox[3];
-    const bool restore_all = (PASS == 2) && allow_lq && (s_flag != 0);
+    t.bx1 = wave_fmin_all(bx1); t.by1 = wave_fmin_all(by1);
+    t.bx2 = wave_fmax_all(bx2); t.by2 = wave_fmax_all(by2);
+}
 
+// Visit, in ascending GT order, every GT of [g_begin, g_end) whose box can overlap the wave's bounding
+// box.  Of those, only the ones whose running rank r satisfies r % nshare == share are handed to
+// f(g, j, rank, gx1, gy1, gx2, gy2, garea) (wave-uniform arguments, j = lane that holds the GT): nshare
+// waves that scan the same GT thereby split the survivors evenly, each still in ascending order.
+// chunk_done(g0, cur) runs after each 64-GT chunk, AFTER the next chunk's loads have been issued, so the
+// memory operations it issues (atomics) are younger than those loads and never delay them.  `cur` is the
+// value of gmax[m0 + g0 + lane] read one chunk earlier (a lower bound of the row maximum, which only
+// grows): a wave whose own maximum does not exceed it can skip its atomic.
+template <typename F, typename D>
+__device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const float4* __restrict__ gt, int m0,
+                                                        const uint32_t* gmax, int g_begin, int g_end, int share,
+                                                        int nshare, F f, D chunk_done) {
+    const int lane = threadIdx.x & 63;
+    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t nxt_max = 0u;
+    if (g_begin + lane < g_end) {
+        nxt = gt[m0 + g_begin + lane];
+        if (gmax) nxt_max = gmax[m0 + g_begin + lane];
+    }
+    int rank = 0;
+    for (int g0 = g_begin; g0 < g_end; g0 += 64) {
+        const float4 gb = nxt;
+        const uint32_t cur = nxt_max;
+        const int gn = g0 + 64 + lane;
+        if (gn < g_end) {                              // prefetch the next chunk
+            nxt = gt[m0 + gn];
+            if (gmax) nxt_max = gmax[m0 + gn];
+        }
+        const bool ok = (g0 + lane < g_end) && !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
+        const float ga = box_area(gb.x, gb.y, gb.z, gb.w);
+        unsigned long long mask = __ballot(ok);
+        while (mask) {
+            const int j = __ffsll(mask) - 1;
+            mask &= mask - 1;
+            const bool mine = (nshare == 1) || (rank % nshare == share);
+            if (mine)
+                f(g0 + j, j, rank, bcast_lane(gb.x, j), bcast_lane(gb.y, j), bcast_lane(gb.z, j), bcast_lane(gb.w, j),
+                  bcast_lane(ga, j));
+            ++rank;
+        }
+        chunk_done(g0, cur);
+    }
+}
+
+// IoU of the wave's anchors with one GT; updates (best, bidx).  With want_max it also returns the ordered
+// key `k` of the maximum over the wave's 256 anchors and, on the FIRST lane that holds an anchor attaining
+// it, the entry word  GT << 9 | several << 8 | local anchor  (0xffffffff on every other lane).  `several`
+// says that more than one anchor of the wave attains the maximum; then store_masks(m0, m1, m2, m3) is called
+// (wave-uniformly) with m_r = lanes whose anchor r attains it.
+template <typename S>
+__device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1, float gy1, float gx2, float gy2,
+                                             float ga, float (&best)[R], int (&bidx)[R], bool want_max, uint32_t& k,
+                                             S store_masks) {
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        v[r] = iou_pair(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
+        if (v[r] > best[r]) { best[r] = v[r]; bidx[r] = g; }
+    }
+    k = 0u;
+    if (!want_max) return 0xffffffffu;
+    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    k = wave_umax_all(ordered_key(m));
+    if (k == kZeroKey) return 0xffffffffu;              // no anchor of the wave overlaps this GT
+    const bool mine = ordered_key(m) == k;
+    int first = -1, cnt = 0;
+#pragma unroll
+    for (int r = R - 1; r >= 0; --r)
+        if (v[r] == m) { first = r; ++cnt; }
+    const unsigned long long am = __ballot(mine);
+    const bool several = (am & (am - 1)) != 0 || __ballot(mine && cnt > 1) != 0;
+    if (several)
+        store_masks(__ballot(mine && v[0] == m), __ballot(mine && v[1] == m), __ballot(mine && v[2] == m),
+                    __ballot(mine && v[3] == m));
+    if (!mine || mbcnt(am) != 0) return 0xffffffffu;
+    return ((uint32_t)g << 9) | (several ? 256u : 0u) | (uint32_t)(first * 64 + (threadIdx.x & 63));
+}
+
+// lanes 0..3 store the four 64-bit attaining masks of a tie entry
+__device__ __forceinline__ void store_tie_masks(unsigned long long* dst, unsigned long long m0, unsigned long long m1,
+                                                unsigned long long m2, unsigned long long m3) {
+    static_assert(R == 4, "four masks per entry");
+    const int lane = threadIdx.x & 63;
+    uint32_t lo = (uint32_t)m0, hi = (uint32_t)(m0 >> 32);
+    if (lane == 1) { lo = (uint32_t)m1; hi = (uint32_t)(m1 >> 32); }
+    if (lane == 2) { lo = (uint32_t)m2; hi = (uint32_t)(m2 >> 32); }
+    if (lane == 3) { lo = (uint32_t)m3; hi = (uint32_t)(m3 >> 32); }
+    if (lane < R) reinterpret_cast<uint2*>(dst)[lane] = make_uint2(lo, hi);
+}
+
+__global__ __launch_bounds__(MT) void match_assign_kernel(
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles,
+    const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
+    float high, float low, long long* __restrict__ matched) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y;
+    // coarse (GT-heavy) pyramid levels sit at the end of the anchor list: start them first
+    const int wt = wtiles - 1 - (int)(blockIdx.x * (MT / 64) + (threadIdx.x >> 6));
+    if (wt < 0) return;
+    const long long base = (long long)wt * WTILE;
+    const int m0 = gt_offsets[b];
+    const int M = gt_offsets[b + 1] - m0;
+    long long* out = matched + (long long)b * n;
+    const long long wslot = (long long)b * wtiles + wt;
+
+    if (M <= 0) {                                   // empty-target guard of compute_loss
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long idx = base + r * 64 + lane;
+            if (idx < n) out[idx] = -1;
+        }
+        if (want_restore && lane == 0) ws.wave_cnt[wslot] = 0;
+        return;
+    }
+
+    WaveTile t;
+    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+    if (M > HEAVY) {                                 // count the GT this tile meets; queue it if heavy
+        int cnt = 0;
+        for (int g0 = 0; g0 < M; g0 += 64) {
+            const int g = g0 + lane;
+            bool ok = g < M;
+            if (ok) {
+                const float4 gb = gt[m0 + g];
+                ok = !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
+            }
+            cnt += __popcll(__ballot(ok));
+        }
+        if (cnt > HEAVY) {
+            if (lane == 0) {                       // queue slot + room for one entry per GT met, in one atomic
+                const unsigned long long old =
+                    atomicAdd(ws.heavy_count + b * 16, (1ull << 32) | (unsigned long long)(want_restore ? cnt : 0));
+                ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int2(wt, (int)(uint32_t)old);
+                if (want_restore) ws.wave_cnt[wslot] = -2;
+            }
+            return;
+        }
+    }
     float best[R];
     int bidx[R];
-    bool restore[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; restore[r] = false; }
+    for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; }
+    int lcount = 0;                                  // wave-uniform
+    uint32_t kreg = 0u;                              // lane j: wave maximum of the IoU with GT g0 + j
 
-    for (int c0 = 0; c0 < M; c0 += GCH) {
-        // ---- stage the GT of this chunk that can overlap the tile, order preserved --------------
-        int base = 0;
+    for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1,
+        [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+            uint32_t k;
+            const long long slot = (long long)lcount * ws.list_stride + wslot;
+            const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
+                                          [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
+                                              store_tie_masks(ws.wave_mask + slot * R, a0, a1, a2, a3);
+                                          });
+            if (want_restore && k > kZeroKey) {        // wave-uniform: this GT overlaps an anchor of the wave
+                kreg = (lane == j) ? k : kreg;
+                if (ent != 0xffffffffu) ws.wave_list[slot] = make_uint2(ent, k);
+                ++lcount;                              // <= HEAVY < LCAP for a light tile
+            }
+        },
+        [&](int g0, uint32_t cur) {
+            if (!want_restore) return;
+            if (kreg > cur) atomicMax(&ws.gt_max_key[m0 + g0 + lane], kreg);
+            kreg = 0u;
+        });
+
+    int* amax = ws.argmax + (long long)b * n;
 #pragma unroll
-        for (int sr = 0; sr < GCH / MT; ++sr) {
-            int g = c0 + sr * MT + tid;
-            bool ok = g < M;
-            float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                gb = gt[m0 + g];
-                ok = !(gb.z <= tb_x1 || gb.x >= tb_x2 || gb.w <= tb_y1 || gb.y >= tb_y2);
-            }
-            uint64_t bal = __ballot(ok);
-            if (lane == 0) s_wcnt[wave] = __popcll(bal);
-            __syncthreads();
-            int pos = base + mbcnt(bal);
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                int c = s_wcnt[w];
-                if (w < wave) pos += c;
-                base += c;
-            }
-            if (ok) {
-                s_g[pos] = gb;
-                GtAux aux;
-                aux.area = box_area(gb.x, gb.y, gb.z, gb.w);
-                aux.gmax = (PASS == 2) ? ordered_key_inv(gt_max_key[m0 + g]) : 0.0f;
-                aux.index = g;
-                aux.pad = 0;
-                s_aux[pos] = aux;
-                if (PASS == 1) s_tilemax[pos] = 0u;
-            }
-            __syncthreads();
+    for (int r = 0; r < R; ++r) {
+        const long long idx = base + r * 64 + lane;
+        if (idx < n) {
+            out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
+            if (want_restore) amax[idx] = bidx[r];
         }
-        const int cnt = base;
+    }
+    if (want_restore && lane == 0) ws.wave_cnt[wslot] = lcount;
+}
 
-        // ---- IoU of the 4 register anchors against every staged GT ------------------------------
-        for (int j = 0; j < cnt; ++j) {
-            const float4 gb = s_g[j];
-            const GtAux aux = s_aux[j];
-            float v[R];
+// Cooperative kernel for the queued heavy tiles: one workgroup of NW waves per tile.  The waves share
+// the tile's 256 anchors, every wave scans all GT but scores only every NW-th survivor; per-anchor
+// (max, first argmax) are merged through LDS (equal maxima -> smaller GT index, which is the first maximal
+// index of the full row).  The entry of the survivor with rank r goes to slot r of the region the assign
+// kernel reserved for the tile, so the kernel needs no atomics besides the per-GT maxima.
+__global__ __launch_bounds__(HT) void match_heavy_kernel(
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles,
+    const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
+    float high, float low, long long* __restrict__ matched) {
+    constexpr int NW = HT / 64;
+    __shared__ float s_best[NW][WTILE];
+    __shared__ int s_bidx[NW][WTILE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const unsigned long long hc = ws.heavy_count[b * 16];
+    const int nheavy = (int)(hc >> 32);
+    const int m0 = gt_offsets[b];
+    const int M = gt_offsets[b + 1] - m0;
+#ifndef OD_EXP
+#define OD_EXP 0
+#endif
+    const bool entries_fit = !(OD_EXP & 2) && (long long)(uint32_t)hc <= entry_cap(M);   // else the restore kernel redoes the image's heavy tiles
+    for (int item = blockIdx.x; item < nheavy; item += gridDim.x) {
+        const int2 qi = ws.heavy_queue[(long long)b * wtiles + item];
+        const int wt = qi.x;
+        const long long wslot = (long long)b * wtiles + wt;
+        const long long ebase = entry_base(b, m0) + qi.y;
+        uint4* entries = ws.heavy_entries + ebase;
+        const long long base = (long long)wt * WTILE;
+        long long* out = matched + (long long)b * n;
+        WaveTile t;
+        load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+        float best[R];
+        int bidx[R];
 #pragma unroll
-            for (int r = 0; r < R; ++r)
-                v[r] = iou_pair(gb.x, gb.y, gb.z, gb.w, aux.area, ax1[r], ay1[r], ax2[r], ay2[r], aarea[r]);
-            if (PASS == 1) {
-                float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-                uint32_t k = wave_umax_lane63(ordered_key(m));
-                if (lane == 63) atomicMax(&s_tilemax[j], k);
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    if (v[r] > best[r]) { best[r] = v[r]; bidx[r] = aux.index; }
-                    restore[r] = restore[r] || (v[r] == aux.gmax);
+        for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; }
+        uint32_t kreg = 0u;
+        for_each_overlapping_gt(t, gt, m0, want_restore ? ws.gt_max_key : nullptr, 0, M, wave, NW,
+            [&](int g, int j, int rank, float gx1, float gy1, float gx2, float gy2, float ga) {
+                uint32_t k;
+                const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
+                                              [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
+                                                  if (entries_fit) store_tie_masks(ws.heavy_mask + (ebase + rank) * R, a0, a1, a2, a3);
+                                              });
+                if (want_restore) {
+                    kreg = (lane == j) ? k : kreg;
+                    // every survivor's slot is written: key 0 (never a maximum) marks "no overlapping anchor"
+                    if (entries_fit) {
+                        if (k == kZeroKey) { if (lane == 0) entries[rank] = make_uint4((uint32_t)wslot, 0u, 0u, 0u); }
+                        else if (ent != 0xffffffffu) entries[rank] = make_uint4((uint32_t)wslot, ent, k, 0u);
+                    }
                 }
+            },
+            [&](int g0, uint32_t cur) {
+                if (!want_restore) return;
+                if (!(OD_EXP & 1) && kreg > cur) atomicMax(&ws.gt_max_key[m0 + g0 + lane], kreg);
+                kreg = 0u;
+            });
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s_best[wave][r * 64 + lane] = best[r]; s_bidx[wave][r * 64 + lane] = bidx[r]; }
+        __syncthreads();
+        if (threadIdx.x < WTILE) {
+            float bb = s_best[0][threadIdx.x];
+            int bi = s_bidx[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float ob = s_best[w][threadIdx.x];
+                const int oi = s_bidx[w][threadIdx.x];
+                if (ob > bb || (ob == bb && oi < bi)) { bb = ob; bi = oi; }
             }
-        }
-        if (PASS == 1) {
-            __syncthreads();
-            const uint32_t zero_key = 0x80000000u;   // ordered_key(+0.0f), the initial per-GT maximum
-            for (int j = tid; j < cnt; j += MT) {
-                uint32_t k = s_tilemax[j];
-                if (k > zero_key) atomicMax(&gt_max_key[m0 + s_aux[j].index], k);
+            const long long idx = base + threadIdx.x;
+            if (idx < n) {
+                out[idx] = (bb < low) ? -1 : ((bb < high) ? -2 : (long long)bi);
+                if (want_restore) ws.argmax[(long long)b * n + idx] = bi;
             }
         }
         __syncthreads();
     }
+}
 
-    if (PASS == 2) {
+// image_flag[b] = 1 if some GT row of image b has maximum IoU exactly 0 (one wave per image)
+__global__ __launch_bounds__(64) void match_flag_kernel(const int* __restrict__ gt_offsets, MatchWs ws) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int m0 = gt_offsets[b], M = gt_offsets[b + 1] - m0;
+    bool any0 = false;
+    for (int g0 = 0; g0 < M; g0 += 256) {
+        uint32_t k[4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            long long idx = tile_base + tid + r * MT;
-            if (idx < n) {
-                long long m = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
-                if (allow_lq && (restore[r] || restore_all)) m = bidx[r];
-                out[idx] = m;
+        for (int u = 0; u < 4; ++u) { const int g = g0 + u * 64 + lane; k[u] = g < M ? ws.gt_max_key[m0 + g] : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) any0 = any0 || (ordered_key_inv(k[u]) == 0.0f);
+    }
+    const unsigned long long m = __ballot(any0);
+    if (lane == 0) {
+        ws.image_flag[b] = m ? 1 : 0;
+        if (m) *ws.any_flag = 1;                     // some image restores every anchor
+    }
+}
+
+// Wave-cooperative re-examination of one tile against the GT range [g_begin, g_end) of its image: the IoUs
+// are recomputed with the same code as in the assign kernel (bit-identical values) and every anchor that
+// attains a GT's global maximum is restored.  All 64 lanes must call it with wave-uniform arguments.
+__device__ __forceinline__ void recheck_segment(const float4* __restrict__ anchors, long long anchor_batch_stride,
+                                                long long n, int wtiles, const float4* __restrict__ gt,
+                                                const int* __restrict__ gt_offsets, const MatchWs& ws, int wslot,
+                                                int g_begin, int g_count, long long* __restrict__ matched) {
+    const int lane = threadIdx.x & 63;
+    const int b = wslot / wtiles, wt = wslot - b * wtiles;
+    const long long base = (long long)wt * WTILE;
+    const int m0 = gt_offsets[b];
+    const int M = gt_offsets[b + 1] - m0;
+    if (g_begin >= M) return;
+    WaveTile t;
+    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+    bool restore[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) restore[r] = false;
+    const int g_end = (g_begin + g_count < M) ? g_begin + g_count : M;
+    for_each_overlapping_gt(t, gt, m0, nullptr, g_begin, g_end, 0, 1,
+        [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+            const float gmax = ordered_key_inv(ws.gt_max_key[m0 + g]);
+            if (!(gmax > 0.0f)) return;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const float v = iou_pair(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
+                restore[r] = restore[r] || (v == gmax);
+            }
+        },
+        [&](int, uint32_t) {});
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long idx = base + r * 64 + lane;
+        if (idx < n && restore[r]) matched[(long long)b * n + idx] = (long long)ws.argmax[(long long)b * n + idx];
+    }
+}
+
+// Restore from the entries.  Blocks [0, light_blocks) take the light tiles, one thread per (entry slot,
+// tile); the remaining blocks take the heavy tiles' entries, one thread per entry.  An entry whose value
+// equals its GT's global maximum restores its anchor, or, if several anchors of the tile tie at that value,
+// every anchor in the entry's attaining masks.  Last, images whose flag is set restore every anchor.  If the heavy-entry buffer was too small (pathological inputs) the heavy blocks re-examine
+// every heavy tile against all GT of its image instead.
+__global__ __launch_bounds__(256) void match_restore_kernel(
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int batch,
+    int light_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
+    long long* __restrict__ matched) {
+    const long long total = (long long)batch * wtiles;
+    const int lane = threadIdx.x & 63;
+    const bool light = (int)blockIdx.x < light_blocks;
+    // light blocks share one index space; heavy blocks are dealt round-robin to the images
+    const int hb = (int)blockIdx.x - light_blocks;
+    const int hblocks = ((int)gridDim.x - light_blocks) / batch;        // heavy blocks per image
+    const int hb_image = light ? 0 : hb % batch;
+    const long long nthreads = (long long)(light ? light_blocks : hblocks) * 256;
+    const long long first = (long long)(light ? (int)blockIdx.x : hb / batch) * 256 + (threadIdx.x & ~63);
+    long long limit = total * LCAP, ebase = 0;
+    bool overflow = false;
+    int nheavy = 0;
+    if (!light) {
+        const unsigned long long hc = ws.heavy_count[hb_image * 16];
+        const int m0 = gt_offsets[hb_image], M = gt_offsets[hb_image + 1] - m0;
+        nheavy = (int)(hc >> 32);
+        overflow = (long long)(uint32_t)hc > entry_cap(M);
+        limit = (overflow || hb / batch >= hblocks) ? 0 : (long long)(uint32_t)hc;
+        ebase = entry_base(hb_image, m0);
+    }
+    for (long long i0 = first; i0 < limit; i0 += nthreads) {
+        const long long i = i0 + lane;
+        uint32_t word = 0u, key = 0u;
+        int wslot = 0;
+        bool have = false;
+        if (i < limit) {
+            if (light) {                                 // slot-major: neighbouring threads, neighbouring tiles
+                const int e = (int)(i / total);
+                wslot = (int)(i - (long long)e * total);
+                if (e < ws.wave_cnt[wslot]) {            // also skips heavy tiles (-2)
+                    const uint2 ent = ws.wave_list[i];
+                    word = ent.x; key = ent.y; have = true;
+                }
+            } else {
+                const uint4 ent = ws.heavy_entries[ebase + i];
+                wslot = (int)ent.x; word = ent.y; key = ent.z; have = true;
             }
         }
+        if (have) {
+            const int b = wslot / wtiles, wt = wslot - b * wtiles;
+            const uint32_t gm = ws.gt_max_key[gt_offsets[b] + (int)(word >> 9)];
+            if (key == gm && !ws.image_flag[b]) {
+                long long* out = matched + (long long)b * n;
+                const int* amax = ws.argmax + (long long)b * n;
+                const long long base = (long long)wt * WTILE;
+                if (word & 256u) {                       // several anchors of the tile tie: walk their masks
+                    const unsigned long long* mp = (light ? ws.wave_mask : ws.heavy_mask) + (ebase + i) * R;
+                    unsigned long long mask[R];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) mask[r] = mp[r];
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        while (mask[r]) {
+                            const long long idx = base + r * 64 + (__ffsll(mask[r]) - 1);
+                            mask[r] &= mask[r] - 1;
+                            if (idx < n) out[idx] = (long long)amax[idx];
+                        }
+                    }
+                } else {
+                    const long long idx = base + (word & 255u);
+                    if (idx < n) out[idx] = (long long)amax[idx];
+                }
+            }
+        }
+    }
+    if (overflow && hb / batch < hblocks && !ws.image_flag[hb_image]) {   // one wave per (heavy tile, 64-GT chunk)
+        const int chunks = (gt_offsets[hb_image + 1] - gt_offsets[hb_image] + 63) >> 6;
+        const long long items = (long long)nheavy * chunks;
+        for (long long q = first >> 6; q < items; q += nthreads >> 6) {
+            const long long h = q / chunks;
+            const int wslot = hb_image * wtiles + ws.heavy_queue[(long long)hb_image * wtiles + h].x;
+            recheck_segment(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, wslot, (int)(q - h * chunks) * 64,
+                            64, matched);
+        }
+    }
+    if (*ws.any_flag == 0) return;                       // no image restores every anchor (the usual case)
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long all_threads = (long long)gridDim.x * 256;
+    for (int b = 0; b < batch; ++b) {
+        if (!ws.image_flag[b] || gt_offsets[b + 1] - gt_offsets[b] <= 0) continue;
+        for (long long idx = tid; idx < n; idx += all_threads) matched[(long long)b * n + idx] = (long long)ws.argmax[(long long)b * n + idx];
     }
 }
 
@@ -286,10 +591,33 @@ __global__ __launch_bounds__(256) void matcher_col_kernel(const float* __restric
 
 }  // namespace
 
-extern "C" size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch) {
-    (void)batch;
-    size_t b = (size_t)(m_total > 0 ? m_total : 0) * sizeof(uint32_t);
-    return (b + 255) & ~(size_t)255;
+static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base(batch, m_total)
+    return (size_t)HCAP_PER_GT * (size_t)(m_total > 0 ? m_total : 0) + 256 * (size_t)batch;
+}
+
+static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[11]) {
+    const size_t wtiles = (size_t)((n + WTILE - 1) / WTILE);
+    const size_t tiles = (size_t)batch * wtiles;
+    off[0] = 0;                                                                     // gt_max_key
+    off[1] = off[0] + align256((size_t)(m_total > 0 ? m_total : 0) * sizeof(uint32_t));   // argmax
+    off[2] = off[1] + align256((size_t)batch * (size_t)n * sizeof(int));            // wave_cnt
+    off[3] = off[2] + align256(tiles * sizeof(int));                                // wave_list
+    off[4] = off[3] + align256(tiles * LCAP * sizeof(uint2));                       // image_flag
+    off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // any_flag (256 B) + heavy_count
+    off[6] = off[5] + 256 + (size_t)batch * 128;                                    // heavy_queue
+    off[7] = off[6] + align256(tiles * sizeof(int2));                               // heavy_entries
+    off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));            // wave_mask
+    off[9] = off[8] + align256(tiles * LCAP * R * sizeof(unsigned long long));      // heavy_mask
+    off[10] = off[9] + align256(heavy_capacity(m_total, batch) * R * sizeof(unsigned long long));
+}
+
+extern "C" size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch, int64_t n) {
+    if (m_total < 0 || batch < 0 || n < 0) return 0;
+    size_t off[11];
+    match_ws_layout(m_total, batch, n, off);
+    return off[10];
 }
 
 extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n,
@@ -301,23 +629,57 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     if (!anchors || !gt_offsets || !matched || (m_total > 0 && !gt_boxes)) return OD_ERR_ARG;
     if (anchor_batch_stride != 0 && anchor_batch_stride < n) return OD_ERR_ARG;
     if (((uintptr_t)anchors & 15) || ((uintptr_t)gt_boxes & 15)) return OD_ERR_ARG;
-    if (m_total > 0x7fffffff || batch > 65535) return OD_ERR_LIMIT;
-    if (workspace_bytes < od_match_retinanet_workspace_bytes(m_total, batch)) return OD_ERR_WORKSPACE;
-    if (m_total > 0 && !workspace) return OD_ERR_ARG;
+    if (m_total >= (1 << 23) || batch > 65535 || n > 0x7fffffffll * 64) return OD_ERR_LIMIT;   // GT index packs into 23 bits
+    if (workspace_bytes < od_match_retinanet_workspace_bytes(m_total, batch, n)) return OD_ERR_WORKSPACE;
+    if (!workspace || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    uint32_t* gt_max_key = (uint32_t*)workspace;
-    dim3 grid((unsigned)((n + TILE - 1) / TILE), (unsigned)batch);
-    if (allow_low_quality && m_total > 0) {
-        OD_HIP(hipMemsetD32Async((hipDeviceptr_t)gt_max_key, (int)0x80000000u, (size_t)m_total, s));
-        OD_LAUNCH(OD_KERNEL_MATCH_GTMAX, s,
-                  hipLaunchKernelGGL(match_retinanet_kernel<1>, grid, dim3(MT), 0, s, (const float4*)anchors,
-                                     (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes,
-                                     gt_offsets, gt_max_key, high, low, 1, (long long*)matched));
-    }
+    size_t off[11];
+    match_ws_layout(m_total, batch, n, off);
+    const int wtiles = (int)((n + WTILE - 1) / WTILE);
+    const long long total_tiles = (long long)batch * wtiles;
+    if (total_tiles > 0x7fffffff || (long long)wtiles * m_total > 0x7fffffffll) return OD_ERR_LIMIT;   // int counters
+    MatchWs ws;
+    char* w = (char*)workspace;
+    ws.gt_max_key = (uint32_t*)(w + off[0]);
+    ws.argmax = (int*)(w + off[1]);
+    ws.wave_cnt = (int*)(w + off[2]);
+    ws.wave_list = (uint2*)(w + off[3]);
+    ws.image_flag = (int*)(w + off[4]);
+    ws.any_flag = (int*)(w + off[5]);
+    ws.heavy_count = (unsigned long long*)(w + off[5] + 256);
+    ws.heavy_queue = (int2*)(w + off[6]);
+    ws.heavy_entries = (uint4*)(w + off[7]);
+    ws.wave_mask = (unsigned long long*)(w + off[8]);
+    ws.heavy_mask = (unsigned long long*)(w + off[9]);
+    ws.list_stride = total_tiles;
+    const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
+    dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
+    if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total, s));
+    OD_HIP(hipMemsetAsync(ws.any_flag, 0, 256 + (size_t)batch * 128, s));
     OD_LAUNCH(OD_KERNEL_MATCH_ASSIGN, s,
-              hipLaunchKernelGGL(match_retinanet_kernel<2>, grid, dim3(MT), 0, s, (const float4*)anchors,
-                                 (long long)anchor_batch_stride, (long long)n, (const float4*)gt_boxes, gt_offsets,
-                                 gt_max_key, high, low, allow_low_quality ? 1 : 0, (long long*)matched));
+              hipLaunchKernelGGL(match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors,
+                                 (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
+                                 gt_offsets, ws, restore, high, low, (long long*)matched));
+    if (m_total > HEAVY) {
+        int heavy_x = 4096 / batch > 64 ? 4096 / batch : 64;
+        if (heavy_x > wtiles) heavy_x = wtiles;
+        OD_LAUNCH(OD_KERNEL_MATCH_HEAVY, s,
+                  hipLaunchKernelGGL(match_heavy_kernel, dim3((unsigned)heavy_x, (unsigned)batch), dim3(HT), 0, s, (const float4*)anchors,
+                                     (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
+                                     gt_offsets, ws, restore, high, low, (long long*)matched));
+    }
+    if (restore) {
+        OD_LAUNCH(OD_KERNEL_MATCH_FLAG, s,
+                  hipLaunchKernelGGL(match_flag_kernel, dim3((unsigned)batch), dim3(64), 0, s, gt_offsets, ws));
+        const long long light_threads = total_tiles * LCAP;
+        const int light_blocks = (int)((light_threads + 255) / 256 < 8192 ? (light_threads + 255) / 256 : 8192);
+        const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
+        OD_LAUNCH(OD_KERNEL_MATCH_RESTORE, s,
+                  hipLaunchKernelGGL(match_restore_kernel, dim3((unsigned)(light_blocks + heavy_entry_blocks)), dim3(256), 0,
+                                     s, (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, wtiles,
+                                     (int)batch, light_blocks, (const float4*)gt_boxes, gt_offsets, ws,
+                                     (long long*)matched));
+    }
     return OD_OK;
 }
 

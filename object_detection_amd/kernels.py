@@ -108,7 +108,7 @@ def match_retinanet(anchors: Tensor, gt_list: Sequence[Tensor], high: float, low
     _require_gpu(gt, "target boxes")
     matched = torch.empty((B, n), dtype=torch.int64, device=dev)
     lib = _C.lib()
-    nbytes = lib.od_match_retinanet_workspace_bytes(m_total, B)
+    nbytes = lib.od_match_retinanet_workspace_bytes(m_total, B, n)
     ws = _workspace(dev, "match", nbytes)
     rc = lib.od_match_retinanet(_ptr(anchors), stride, n, _ptr(gt), _ptr(offsets), m_total, B, float(high),
                                 float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws), ws.numel(),

@@ -41,7 +41,7 @@ def test_header_constants_match_python():
 
 def test_workspace_sizes_host_only():
     lib = _C.lib()
-    assert lib.od_match_retinanet_workspace_bytes(2000, 64) >= 2000 * 4
+    assert lib.od_match_retinanet_workspace_bytes(2000, 64, 786240) >= 2000 * 4 + 64 * 786240 * 4
     assert lib.od_matcher_workspace_bytes(10, 100) >= 40
     sizes = (ctypes.c_int64 * 2)(1000, 10)
     nbytes = lib.od_select_candidates_workspace_bytes(sizes, 2, 3, 4)

@@ -38,9 +38,13 @@ def main():
     ap.add_argument("--what", default="all")
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--gt", type=int, default=100)
+    ap.add_argument("--levels", type=int, default=6, help="use only the finest LEVELS pyramid levels")
+    ap.add_argument("--lib", default=None, help="experimental build of libod_boxes.so to load instead")
     args = ap.parse_args()
+    if args.lib:
+        _C.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device("cuda:0")
-    cfg = dataclasses.replace(synthetic.CFG2, batch=args.batch, num_gt=args.gt)
+    cfg = dataclasses.replace(synthetic.CFG2, batch=args.batch, num_gt=args.gt, grids=synthetic.CFG2.grids[:args.levels])
     sizes = synthetic.level_sizes(cfg)
     ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
     grids = [(g, g) for g in cfg.grids]
@@ -51,6 +55,16 @@ def main():
         targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)
         gts = [t["boxes"].to(dev) for t in targets]
         res["match"] = timed(lambda: kernels.match_retinanet(anchors, gts, 0.6, 0.5, True))
+        # debug: device counters of the last call (layout mirrors match_ws_layout in od_match.hip)
+        a256 = lambda v: (v + 255) & ~255
+        m_total = sum(int(g.shape[0]) for g in gts)
+        n = anchors.shape[-2]
+        tiles = len(gts) * ((n + 255) // 256)
+        off = a256(m_total * 4) + a256(len(gts) * n * 4) + a256(tiles * 4) + a256(tiles * 24 * 8) + a256(len(gts) * 4)
+        ws = kernels._workspaces[(anchors.device.index, "match")]
+        hc = ws[off + 256:off + 256 + len(gts) * 128].view(torch.int64)[::16]
+        res["match_counters"] = {"heavy_tiles": int((hc >> 32).sum()), "heavy_entries": int((hc & 0xffffffff).sum()),
+                                 "tiles": tiles}
     if args.what in ("all", "post", "nms", "select"):
         head = synthetic.make_head_outputs(cfg)
         cls = head["cls_logits"].to(dev)
