@@ -43,10 +43,14 @@ constexpr int LCAP = HEAVY;      // entries of a light wave tile: one per GT wit
 #define OD_HT 256
 #endif
 constexpr int HT = OD_HT;        // threads of the cooperative (heavy tile) workgroup
+#ifndef OD_GSTRIDE
+#define OD_GSTRIDE 32
+#endif
+constexpr int GSTRIDE = OD_GSTRIDE;   // words between two GT maxima: atomics on one 128-byte line serialise
 constexpr int HCAP_PER_GT = 160;  // heavy-entry buffer capacity = HCAP_PER_GT * m_total + 4096
 
 struct MatchWs {                 // workspace carve-up (all device pointers)
-    uint32_t* gt_max_key;        // [m_total]          ordered-key maximum IoU of every GT row
+    uint32_t* gt_max_key;        // [m_total * GSTRIDE] ordered-key maximum IoU of every GT row, one per GSTRIDE words
     int* argmax;                 // [batch, n]         per-anchor argmax before thresholding
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
     uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT << 9 | several << 8 | local anchor, y = value key
@@ -106,7 +110,7 @@ __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const
     uint32_t nxt_max = 0u;
     if (g_begin + lane < g_end) {
         nxt = gt[m0 + g_begin + lane];
-        if (gmax) nxt_max = gmax[m0 + g_begin + lane];
+        if (gmax) nxt_max = gmax[(long long)(m0 + g_begin + lane) * GSTRIDE];
     }
     int rank = 0;
     for (int g0 = g_begin; g0 < g_end; g0 += 64) {
@@ -115,7 +119,7 @@ __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const
         const int gn = g0 + 64 + lane;
         if (gn < g_end) {                              // prefetch the next chunk
             nxt = gt[m0 + gn];
-            if (gmax) nxt_max = gmax[m0 + gn];
+            if (gmax) nxt_max = gmax[(long long)(m0 + gn) * GSTRIDE];
         }
         const bool ok = (g0 + lane < g_end) && !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
         const float ga = box_area(gb.x, gb.y, gb.z, gb.w);
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         },
         [&](int g0, uint32_t cur) {
             if (!want_restore) return;
-            if (kreg > cur) atomicMax(&ws.gt_max_key[m0 + g0 + lane], kreg);
+            if (kreg > cur) atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
             kreg = 0u;
         });
 
@@ -284,10 +288,7 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
     const int nheavy = (int)(hc >> 32);
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
-#ifndef OD_EXP
-#define OD_EXP 0
-#endif
-    const bool entries_fit = !(OD_EXP & 2) && (long long)(uint32_t)hc <= entry_cap(M);   // else the restore kernel redoes the image's heavy tiles
+    const bool entries_fit = (long long)(uint32_t)hc <= entry_cap(M);   // else the restore kernel redoes the image's heavy tiles
     for (int item = blockIdx.x; item < nheavy; item += gridDim.x) {
         const int2 qi = ws.heavy_queue[(long long)b * wtiles + item];
         const int wt = qi.x;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
             },
             [&](int g0, uint32_t cur) {
                 if (!want_restore) return;
-                if (!(OD_EXP & 1) && kreg > cur) atomicMax(&ws.gt_max_key[m0 + g0 + lane], kreg);
+                if (kreg > cur) atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
                 kreg = 0u;
             });
 #pragma unroll
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(64) void match_flag_kernel(const int* __restrict__ 
     for (int g0 = 0; g0 < M; g0 += 256) {
         uint32_t k[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int g = g0 + u * 64 + lane; k[u] = g < M ? ws.gt_max_key[m0 + g] : 0xffffffffu; }
+        for (int u = 0; u < 4; ++u) { const int g = g0 + u * 64 + lane; k[u] = g < M ? ws.gt_max_key[(long long)(m0 + g) * GSTRIDE] : 0xffffffffu; }
 #pragma unroll
         for (int u = 0; u < 4; ++u) any0 = any0 || (ordered_key_inv(k[u]) == 0.0f);
     }
@@ -386,7 +387,7 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
     const int g_end = (g_begin + g_count < M) ? g_begin + g_count : M;
     for_each_overlapping_gt(t, gt, m0, nullptr, g_begin, g_end, 0, 1,
         [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
-            const float gmax = ordered_key_inv(ws.gt_max_key[m0 + g]);
+            const float gmax = ordered_key_inv(ws.gt_max_key[(long long)(m0 + g) * GSTRIDE]);
             if (!(gmax > 0.0f)) return;
 #pragma unroll
             for (int r = 0; r < R; ++r) {
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
         }
         if (have) {
             const int b = wslot / wtiles, wt = wslot - b * wtiles;
-            const uint32_t gm = ws.gt_max_key[gt_offsets[b] + (int)(word >> 9)];
+            const uint32_t gm = ws.gt_max_key[(long long)(gt_offsets[b] + (int)(word >> 9)) * GSTRIDE];
             if (key == gm && !ws.image_flag[b]) {
                 long long* out = matched + (long long)b * n;
                 const int* amax = ws.argmax + (long long)b * n;
@@ -601,7 +602,7 @@ static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t of
     const size_t wtiles = (size_t)((n + WTILE - 1) / WTILE);
     const size_t tiles = (size_t)batch * wtiles;
     off[0] = 0;                                                                     // gt_max_key
-    off[1] = off[0] + align256((size_t)(m_total > 0 ? m_total : 0) * sizeof(uint32_t));   // argmax
+    off[1] = off[0] + align256((size_t)(m_total > 0 ? m_total : 0) * GSTRIDE * sizeof(uint32_t));   // argmax
     off[2] = off[1] + align256((size_t)batch * (size_t)n * sizeof(int));            // wave_cnt
     off[3] = off[2] + align256(tiles * sizeof(int));                                // wave_list
     off[4] = off[3] + align256(tiles * LCAP * sizeof(uint2));                       // image_flag
@@ -654,7 +655,7 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     ws.list_stride = total_tiles;
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
     dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
-    if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total, s));
+    if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total * GSTRIDE, s));
     OD_HIP(hipMemsetAsync(ws.any_flag, 0, 256 + (size_t)batch * 128, s));
     OD_LAUNCH(OD_KERNEL_MATCH_ASSIGN, s,
               hipLaunchKernelGGL(match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors,

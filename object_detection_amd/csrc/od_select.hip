@@ -4,15 +4,20 @@
 //   anchor = idx // C; label = idx % C; decode_single(reg[anchor], anchors[anchor]); clip_boxes_to_image
 // (reference trigger object_detection/train.py:84, object_detection/predict.py:61; knobs predict.py:44-45).
 //
-// Kernel 1 (filter_kernel, HBM-bound stream): every workgroup owns one 8192-element chunk of one
-// (image, level) logit slab, reads it once with 16-byte loads, and appends the survivors as unique
-// 64-bit keys  (score_bits << 32) | (0xFFFFFFFF - flat_index)  to the chunk's own segment of the
-// workspace (no global atomics; one LDS counter per workgroup).  Larger key = better candidate, and
-// the low word makes the adopted tie rule (equal score -> lower flat index first) part of the order.
+// Kernel 1 (filter_kernel, a read-once stream): every workgroup owns one 8192-element chunk of one
+// (image, level) logit slab and requests all of it with 16-byte loads before the first use.  A logit that
+// cannot reach the threshold is rejected by one compare; the rest get the specified sigmoid.  Survivors
+// become unique 64-bit keys  (score_bits << 32) | (0xFFFFFFFF - flat_index): larger key = better
+// candidate, and the low word makes the adopted tie rule (equal score -> lower flat index first) part of
+// the order.  Each wave stages its survivors in LDS, reserves that many slots of the (image, level) key
+// array with one global atomic, and copies them there, so the array is dense (its order is irrelevant:
+// keys are unique and get sorted).
 //
-// Kernel 2 (select_kernel, one 1024-thread workgroup per (image, level)): radix-descends on the key
-// with 4096-bin LDS histograms until the keys above the cut fit in LDS, gathers them, bitonic-sorts
-// them in LDS, and decodes + clips the first K straight into the padded candidate arrays.
+// Kernel 2 (select_kernel, one 1024-thread workgroup per (image, level)): if all keys fit in LDS they are
+// read once, histogrammed on the fly, cut at the K-th key by one 4096-bin radix step inside LDS, and the
+// few keys above the cut are bitonic-sorted.  Otherwise the radix descent runs over the dense global array
+// (one coalesced pass per 12 bits) until the keys above the cut fit.  The first K sorted keys are decoded
+// and clipped straight into the padded candidate arrays.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -24,9 +29,10 @@ constexpr int ST = 256;            // filter workgroup
 constexpr int CHUNK = 8192;        // logits per filter workgroup (32 KB)
 constexpr int SEL_T = 1024;        // select workgroup
 constexpr int CAP = 8192;          // keys held in LDS by the select kernel
+constexpr int CAP2 = 2048;         // keys above the radix cut that are sorted separately
 constexpr int HBITS = 12;
 constexpr int HBINS = 1 << HBITS;  // histogram bins per radix level
-constexpr int DIRECT = 2048;       // survivors <= DIRECT: skip the histogram, sort everything
+constexpr int CSTRIDE = 64;        // one key counter per 256 bytes: atomics on one cache line serialise
 
 struct FilterParams {
     int num_levels;
@@ -35,6 +41,8 @@ struct FilterParams {
     int total_chunks;                       // per image
     int chunk_start[OD_MAX_LEVELS + 1];     // first chunk id of each level
     long long level_elems[OD_MAX_LEVELS];   // N_l * C
+    long long key_off[OD_MAX_LEVELS];       // first key slot of the level inside an image's key array
+    long long keys_per_image;
     const float* cls[OD_MAX_LEVELS];
     long long cls_stride[OD_MAX_LEVELS];
     const float* ctr[OD_MAX_LEVELS];
@@ -55,7 +63,8 @@ struct SelectParams {
     long long reg_stride[OD_MAX_LEVELS];
     const float* anchors[OD_MAX_LEVELS];
     long long anchor_stride[OD_MAX_LEVELS];
-    int chunk_start[OD_MAX_LEVELS + 1];
+    long long key_off[OD_MAX_LEVELS];
+    long long keys_per_image;
 };
 
 __device__ __forceinline__ float score_of(const FilterParams& p, int l, int b, float x, long long flat) {
@@ -68,11 +77,18 @@ __device__ __forceinline__ float score_of(const FilterParams& p, int l, int b, f
     return s;
 }
 
-__global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ seg_keys,
-                                                    int* __restrict__ seg_count) {
-    __shared__ int s_count;
+// Every wave works on its own: it tests its 2048 logits against the prefilter bound, then scores the few
+// that remain one per lane and round (a single sigmoid site, operands picked from the register file by a
+// select tree), stages the survivors' keys in its LDS buffer, and appends them to the (image, level)
+// array with one global atomic per flush.
+__global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
+                                                    unsigned int* __restrict__ key_count) {
+    constexpr int WCAP = 256;                      // staged keys per wave
+    constexpr int ITERS = CHUNK / (ST * 4);
+    static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
+    __shared__ unsigned long long s_buf[ST / 64][WCAP];
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
     const int b = blockIdx.y;
     int l = 0;
@@ -82,76 +98,140 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     const long long E = p.level_elems[l];
     const long long e0 = (long long)(chunk - p.chunk_start[l]) * CHUNK;
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
-    unsigned long long* seg = seg_keys + ((long long)b * p.total_chunks + chunk) * CHUNK;
-    if (tid == 0) s_count = 0;
-    __syncthreads();
-
     const bool vec_ok = (((uintptr_t)(src + e0)) & 15) == 0;
     const long long rem = E - e0;
     const int len = rem < CHUNK ? (int)rem : CHUNK;
 
-#pragma unroll 2
-    for (int it = 0; it < CHUNK / (ST * 4); ++it) {
-        float x[4];
-        int off[4];
-        const int blk = it * ST * 4;
-        if (vec_ok && blk + ST * 4 <= len) {
-            const float4 v = *reinterpret_cast<const float4*>(src + e0 + blk + tid * 4);
-            x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) off[k] = blk + tid * 4 + k;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                off[k] = blk + k * ST + tid;
-                x[k] = (off[k] < len) ? src[e0 + off[k]] : -__builtin_inff();
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            bool pass = false;
-            float s = 0.0f;
-            if (off[k] < len && (!p.prefilter || !(x[k] <= p.pre_logit))) {
-                s = score_of(p, l, b, x[k], e0 + off[k]);
-                pass = s > p.thresh;
-            }
-            const uint64_t bal = __ballot(pass);
-            if (bal) {
-                int base = 0;
-                const int first = __ffsll((unsigned long long)bal) - 1;
-                if (lane == first) base = atomicAdd(&s_count, __popcll(bal));
-                base = __builtin_amdgcn_readlane(base, first);
-                if (pass) {
-                    const unsigned long long flat = (unsigned long long)(e0 + off[k]);
-                    seg[base + mbcnt(bal)] = ((unsigned long long)f2u(s) << 32) | (0xFFFFFFFFull - flat);
-                }
-            }
-        }
+    // thread t owns elements it*1024 + t*4 + k, held in v<it>.<k>; all loads are requested before the first
+    // use: the kernel is a read-once stream and needs its bytes in flight.  (Named registers, no array: an
+    // array read through selects would be placed in scratch memory.)
+    typedef float vec4f __attribute__((ext_vector_type(4)));
+    vec4f v0, v1, v2, v3, v4, v5, v6, v7;
+    if (vec_ok && len == CHUNK) {
+        const vec4f* vp = reinterpret_cast<const vec4f*>(src + e0 + tid * 4);
+        v0 = __builtin_nontemporal_load(vp + 0 * ST); v1 = __builtin_nontemporal_load(vp + 1 * ST);
+        v2 = __builtin_nontemporal_load(vp + 2 * ST); v3 = __builtin_nontemporal_load(vp + 3 * ST);
+        v4 = __builtin_nontemporal_load(vp + 4 * ST); v5 = __builtin_nontemporal_load(vp + 5 * ST);
+        v6 = __builtin_nontemporal_load(vp + 6 * ST); v7 = __builtin_nontemporal_load(vp + 7 * ST);
+    } else {
+        auto ld4 = [&](int it) {
+            vec4f r;
+            const int off = it * ST * 4 + tid * 4;
+            r.x = (off + 0 < len) ? src[e0 + off + 0] : -__builtin_inff();
+            r.y = (off + 1 < len) ? src[e0 + off + 1] : -__builtin_inff();
+            r.z = (off + 2 < len) ? src[e0 + off + 2] : -__builtin_inff();
+            r.w = (off + 3 < len) ? src[e0 + off + 3] : -__builtin_inff();
+            return r;
+        };
+        v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
     }
-    __syncthreads();
-    if (tid == 0) seg_count[(long long)b * p.total_chunks + chunk] = s_count;
+    const float pre = p.pre_logit;
+    unsigned int pending = 0u;                     // bit it*4+k: that element may reach the threshold
+    auto mark = [&](const vec4f& v, int it) {
+        unsigned int m = 0u;
+        m |= !(v.x <= pre) ? 1u : 0u; m |= !(v.y <= pre) ? 2u : 0u;
+        m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
+        pending |= m << (it * 4);
+    };
+    if (p.prefilter) {
+        mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
+    } else {
+        pending = 0xffffffffu;                     // threshold <= 0: every element is scored
+    }
+    if (len < CHUNK) {
+        unsigned int in_range = 0u;
+#pragma unroll
+        for (int i = 0; i < ITERS * 4; ++i)
+            in_range |= ((i >> 2) * ST * 4 + tid * 4 + (i & 3) < len) ? (1u << i) : 0u;
+        pending &= in_range;
+    }
+
+    unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
+    unsigned int* counter = key_count + ((long long)b * p.num_levels + l) * CSTRIDE;
+    unsigned long long* buf = s_buf[wave];
+    int staged = 0;                                // wave-uniform
+    auto flush = [&]() {
+        if (staged == 0) return;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(counter, (unsigned int)staged);
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
+        for (int i = lane; i < staged; i += 64) dst[base + i] = buf[i];
+        staged = 0;
+    };
+    while (__ballot(pending != 0u)) {
+        const bool active = pending != 0u;
+        const int e = active ? (__ffs(pending) - 1) : 0;
+        pending &= pending - 1u;
+        // xe = element e through a select tree (a dynamically indexed array would live in scratch memory)
+        const bool b0 = e & 1, b1 = e & 2;
+        const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
+        const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
+        const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
+        const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
+        const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
+        const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
+        const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
+        const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
+        const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
+        const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
+        const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
+        const float xe = b4 ? h1 : h0;
+        const long long flat = e0 + (e >> 2) * (ST * 4) + tid * 4 + (e & 3);
+        float sc = 0.0f;
+        bool pass = false;
+        if (active) {
+            sc = score_of(p, l, b, xe, flat);
+            pass = sc > p.thresh;
+        }
+        const uint64_t bal = __ballot(pass);
+        const int n = __popcll(bal);
+        if (staged + n > WCAP) flush();
+        if (pass) buf[staged + mbcnt(bal)] = ((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat);
+        staged += n;
+    }
+    flush();
 }
 
 // ---- block-wide helpers for the select kernel ----------------------------------------------------
-__device__ __forceinline__ int block_sum(int v, int* s_tmp) {   // s_tmp: 17 ints
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int w = (int)wave_sum_all((uint32_t)v);
-    __syncthreads();
-    if (lane == 0) s_tmp[wave] = w;
-    __syncthreads();
-    int t = 0;
+// Finds, from the top, the histogram bin in which the running count reaches `need`.
+// Returns (bin, keys in the bins above it, keys in it) through s_tmp[16..18]; all threads must call it.
+__device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb, int need, int* s_tmp) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (nb + SEL_T - 1) / SEL_T;     // 4 when nb = 4096, else 1 (nb <= 1024)
+    int local = 0;
+    for (int i = 0; i < per; ++i) { const int bin = tid * per + i; if (bin < nb) local += (int)s_hist[bin]; }
+    int suf = local;                              // inclusive suffix sum over the lanes of the wave
 #pragma unroll
-    for (int i = 0; i < SEL_T / 64; ++i) t += s_tmp[i];
-    return t;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
+    if (lane == 0) s_tmp[wave] = suf;             // wave total
+    __syncthreads();
+    int higher = 0;                               // keys in waves above this one
+    for (int i = wave + 1; i < SEL_T / 64; ++i) higher += s_tmp[i];
+    const int above_me = higher + suf - local;    // keys in bins strictly above my bins
+    if (above_me < need && need <= above_me + local) {
+        int acc = above_me;
+        for (int i = per - 1; i >= 0; --i) {
+            const int bin = tid * per + i;
+            if (bin >= nb) continue;
+            const int h = (int)s_hist[bin];
+            if (acc < need && need <= acc + h) { s_tmp[16] = bin; s_tmp[17] = acc; s_tmp[18] = h; }
+            acc += h;
+        }
+    }
+    __syncthreads();
 }
 
-template <typename F>
-__device__ __forceinline__ void for_each_key(const unsigned long long* keys, const int* counts, int nseg, F f) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int s = wave; s < nseg; s += SEL_T / 64) {
-        const int c = counts[s];
-        const unsigned long long* k = keys + (long long)s * CHUNK;
-        for (int e = lane; e < c; e += 64) f(k[e]);
+// wave-aggregated append of `k` (where take) to dst[*counter ...), capacity cap
+__device__ __forceinline__ void lds_append(bool take, unsigned long long k, unsigned long long* dst, int* counter, int cap) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t bal = __ballot(take);
+    if (bal) {
+        int base = 0;
+        const int first = __ffsll((unsigned long long)bal) - 1;
+        if (lane == first) base = atomicAdd(counter, __popcll(bal));
+        base = __builtin_amdgcn_readlane(base, first);
+        const int pos = base + mbcnt(bal);
+        if (take && pos < cap) dst[pos] = k;
     }
 }
 
@@ -193,9 +273,9 @@ __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b
     if (cand_index) cand_index[slot] = (long long)flat;
 }
 
-__global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_levels, int total_chunks,
-                                                       const unsigned long long* __restrict__ seg_keys,
-                                                       const int* __restrict__ seg_count,
+__global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_levels,
+                                                       const unsigned long long* __restrict__ all_keys,
+                                                       const unsigned int* __restrict__ key_count,
                                                        const int* __restrict__ image_hw,
                                                        float* __restrict__ cand_boxes,
                                                        float* __restrict__ cand_scores,
@@ -203,29 +283,64 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
                                                        long long* __restrict__ cand_index,
                                                        int* __restrict__ cand_count) {
     __shared__ unsigned long long s_keys[CAP];
+    __shared__ unsigned long long s_sel[CAP2];
     __shared__ unsigned int s_hist[HBINS];
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
     const int l = blockIdx.x, b = blockIdx.y;
-    const int c_first = p.chunk_start[l];
-    const int nseg = p.chunk_start[l + 1] - c_first;
-    const int* counts = seg_count + (long long)b * total_chunks + c_first;
-    const unsigned long long* keys = seg_keys + ((long long)b * total_chunks + c_first) * CHUNK;
+    const unsigned int total = key_count[(long long)(b * num_levels + l) * CSTRIDE];
+    const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     const int K = p.topk;
-
-    int mine = 0;
-    for (int s = tid; s < nseg; s += SEL_T) mine += counts[s];
-    const int total = block_sum(mine, s_tmp);
     if (total == 0) {
         if (tid == 0) cand_count[b * num_levels + l] = 0;
         return;
     }
+    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
+    if (tid == 0) { s_tmp[20] = 0; s_tmp[21] = 0; }
+    __syncthreads();
 
-    unsigned long long lo = 0;   // gather threshold: keys >= lo are taken into LDS
-    int n_ge = total;
-    if (total > DIRECT && total > K) {
-        lo = p.lo0;
+    unsigned long long* sorted = s_keys;       // where the keys to sort end up
+    int cnt;
+    if (total <= (unsigned int)CAP) {
+        // ---- everything fits: one pass over the keys, histogram of the first radix digit on the fly ------
+        const int d = p.w0 < HBITS ? p.w0 : HBITS;
+        const int shift = p.w0 - d;
+        const bool cut = (int)total > K && (int)total > CAP2 / 2;
+        for (int i = tid; i < (int)total; i += SEL_T) {
+            const unsigned long long k = keys[i];
+            s_keys[i] = k;
+            if (cut) {
+                unsigned long long bin = (k - p.lo0) >> shift;    // keys lie in [lo0, lo0 + 2^w0)
+                if (bin > (unsigned long long)(HBINS - 1)) bin = HBINS - 1;
+                atomicAdd(&s_hist[(unsigned int)bin], 1u);
+            }
+        }
+        __syncthreads();
+        cnt = (int)total;
+        if (cut) {
+            find_cut_bin(s_hist, 1 << d, K, s_tmp);
+            const int bstar = s_tmp[16], n_ge = s_tmp[17] + s_tmp[18];
+            if (n_ge <= CAP2) {                                    // else: too many equal digits, sort everything
+                for (int i0 = 0; i0 < cnt; i0 += SEL_T) {
+                    const int i = i0 + tid;
+                    unsigned long long k = 0;
+                    bool take = false;
+                    if (i < cnt) {
+                        k = s_keys[i];
+                        unsigned long long bin = (k - p.lo0) >> shift;
+                        if (bin > (unsigned long long)(HBINS - 1)) bin = HBINS - 1;
+                        take = (int)bin >= bstar;
+                    }
+                    lds_append(take, k, s_sel, &s_tmp[20], CAP2);
+                }
+                __syncthreads();
+                cnt = n_ge;
+                sorted = s_sel;
+            }
+        }
+    } else {
+        // ---- radix descent over the dense global key array until the keys above the cut fit in LDS -------
+        unsigned long long lo = p.lo0;
         int w = p.w0;
         int need = K;            // how many of the keys inside [lo, lo + 2^w) are still wanted
         while (true) {
@@ -234,91 +349,61 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             const int nb = 1 << d;
             for (int i = tid; i < nb; i += SEL_T) s_hist[i] = 0;
             __syncthreads();
-            const unsigned long long lo_c = lo;
             const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
-            for_each_key(keys, counts, nseg, [&](unsigned long long k) {
-                if (k >= lo_c && (k - lo_c) <= span) atomicAdd(&s_hist[(unsigned int)((k - lo_c) >> shift)], 1u);
-            });
-            __syncthreads();
-            // suffix scan: thread t owns bins [t*per, t*per+per); find the bin where the count from the top reaches `need`
-            const int per = (nb + SEL_T - 1) / SEL_T;     // 4 when nb = 4096, else 1 (nb <= 1024)
-            int local = 0;
-            for (int i = 0; i < per; ++i) { int bin = tid * per + i; if (bin < nb) local += (int)s_hist[bin]; }
-            // inclusive suffix sum over threads: wave-level then across waves
-            int suf = local;
+            for (unsigned int i0 = 0; i0 < total; i0 += SEL_T * 4) {       // 4 independent loads per thread
+                unsigned long long k[4];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { int t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
-            if (lane == 0) s_tmp[wave] = suf;             // wave total
-            __syncthreads();
-            int higher = 0;                               // keys in waves above this one
-            for (int i = wave + 1; i < SEL_T / 64; ++i) higher += s_tmp[i];
-            const int above_me = higher + suf - local;    // keys in bins strictly above my bins
-            __syncthreads();
-            if (above_me < need && need <= above_me + local) {
-                int acc = above_me;
-                for (int i = per - 1; i >= 0; --i) {
-                    const int bin = tid * per + i;
-                    if (bin >= nb) continue;
-                    const int h = (int)s_hist[bin];
-                    if (acc < need && need <= acc + h) { s_tmp[16] = bin; s_tmp[17] = acc; s_tmp[18] = h; }
-                    acc += h;
-                }
+                for (int u = 0; u < 4; ++u) { const unsigned int i = i0 + u * SEL_T + tid; k[u] = i < total ? keys[i] : 0ull; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
             }
             __syncthreads();
+            find_cut_bin(s_hist, nb, need, s_tmp);
             const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18];
             __syncthreads();
             lo = lo + ((unsigned long long)bstar << shift);
             w = shift;
-            n_ge = (K - need) + above + h;
+            const int n_ge = (K - need) + above + h;
             need -= above;
             if (n_ge <= CAP || w == 0) break;
         }
+        for (unsigned int i0 = 0; i0 < total; i0 += SEL_T * 4) {
+            unsigned long long k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const unsigned int i = i0 + u * SEL_T + tid; k[u] = i < total ? keys[i] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lds_append(k[u] >= lo && k[u] != 0ull, k[u], s_keys, &s_tmp[20], CAP);
+        }
+        __syncthreads();
+        cnt = s_tmp[20];
+        if (cnt > CAP) cnt = CAP;   // unreachable for unique keys; keeps LDS accesses in bounds
     }
 
-    // ---- gather keys >= lo into LDS ------------------------------------------------------------------
-    if (tid == 0) s_tmp[20] = 0;
-    __syncthreads();
-    {
-        const unsigned long long lo_c = lo;
-        const int lane_ = lane;
-        for (int s = wave; s < nseg; s += SEL_T / 64) {
-            const int c = counts[s];
-            const unsigned long long* kp = keys + (long long)s * CHUNK;
-            for (int e0 = 0; e0 < c; e0 += 64) {
-                const int e = e0 + lane_;
-                unsigned long long k = 0;
-                bool take = false;
-                if (e < c) { k = kp[e]; take = k >= lo_c; }
-                const uint64_t bal = __ballot(take);
-                if (bal) {
-                    int base = 0;
-                    const int first = __ffsll((unsigned long long)bal) - 1;
-                    if (lane_ == first) base = atomicAdd(&s_tmp[20], __popcll(bal));
-                    base = __builtin_amdgcn_readlane(base, first);
-                    const int pos = base + mbcnt(bal);
-                    if (take && pos < CAP) s_keys[pos] = k;
-                }
-            }
-        }
-    }
-    __syncthreads();
-    int cnt = s_tmp[20];
-    if (cnt > CAP) cnt = CAP;   // unreachable for unique keys; keeps LDS accesses in bounds
     int n_pad = 64;
     while (n_pad < cnt) n_pad <<= 1;
-    for (int i = cnt + tid; i < n_pad; i += SEL_T) s_keys[i] = 0ull;
+    for (int i = cnt + tid; i < n_pad; i += SEL_T) sorted[i] = 0ull;
     __syncthreads();
 
-    // ---- bitonic sort, descending -------------------------------------------------------------------
+    // ---- bitonic sort, descending; each thread loads all its pairs of a stage, then stores ---------------
+    constexpr int PQ = CAP / 2 / SEL_T;
     for (int k = 2; k <= n_pad; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n_pad; i += SEL_T) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s_keys[i], c2 = s_keys[ixj];
-                    const bool desc = (i & k) == 0;
-                    if ((a < c2) == desc) { s_keys[i] = c2; s_keys[ixj] = a; }
-                }
+            unsigned long long x[PQ], y[PQ];
+            int lo_i[PQ];
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                const int pr = tid + q * SEL_T;                           // pair index
+                lo_i[q] = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));        // insert a 0 bit at log2(j)
+                const bool on = pr < (n_pad >> 1);
+                x[q] = on ? sorted[lo_i[q]] : 0ull;
+                y[q] = on ? sorted[lo_i[q] | j] : 0ull;
+            }
+#pragma unroll
+            for (int q = 0; q < PQ; ++q) {
+                const int pr = tid + q * SEL_T;
+                const bool desc = (lo_i[q] & k) == 0;
+                if (pr < (n_pad >> 1) && ((x[q] < y[q]) == desc)) { sorted[lo_i[q]] = y[q]; sorted[lo_i[q] | j] = x[q]; }
             }
             __syncthreads();
         }
@@ -326,7 +411,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
 
     const int n_out = cnt < K ? cnt : K;
     for (int r = tid; r < n_out; r += SEL_T)
-        decode_store(p, l, b, s_keys[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
+        decode_store(p, l, b, sorted[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
     if (tid == 0) cand_count[b * num_levels + l] = n_out;
 }
 
@@ -361,23 +446,29 @@ __global__ __launch_bounds__(256) void decode_kernel(const float4* __restrict__ 
 struct Layout {
     int total_chunks;
     int chunk_start[OD_MAX_LEVELS + 1];
+    long long key_off[OD_MAX_LEVELS];
+    long long keys_per_image;
     size_t keys_bytes, counts_bytes;
 };
 
 bool make_layout(const int64_t* level_size, int num_levels, int batch, int num_classes, Layout* lay) {
-    long long chunks = 0;
+    long long chunks = 0, slots = 0;
+    for (int l = 0; l < OD_MAX_LEVELS; ++l) lay->key_off[l] = 0;
     for (int l = 0; l < num_levels; ++l) {
         if (level_size[l] < 0) return false;
         long long e = level_size[l] * (long long)num_classes;
         if (e > 0xFFFFFFFFll) return false;
         lay->chunk_start[l] = (int)chunks;
+        lay->key_off[l] = slots;
         chunks += (e + CHUNK - 1) / CHUNK;
+        slots += (e + 31) & ~31ll;                 // every level starts on a 256-byte boundary
         if (chunks > 0x3fffffff) return false;
     }
     for (int l = num_levels; l <= OD_MAX_LEVELS; ++l) lay->chunk_start[l] = (int)chunks;
     lay->total_chunks = (int)chunks;
-    lay->keys_bytes = ((size_t)batch * (size_t)chunks * CHUNK * 8 + 255) & ~(size_t)255;
-    lay->counts_bytes = ((size_t)batch * (size_t)chunks * 4 + 255) & ~(size_t)255;
+    lay->keys_per_image = slots;
+    lay->keys_bytes = ((size_t)batch * (size_t)slots * 8 + 255) & ~(size_t)255;
+    lay->counts_bytes = (size_t)batch * (size_t)num_levels * CSTRIDE * 4;
     return true;
 }
 
@@ -415,8 +506,8 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
     if (workspace_bytes < lay.keys_bytes + lay.counts_bytes) return OD_ERR_WORKSPACE;
     if (((uintptr_t)workspace & 255) || ((uintptr_t)cand_boxes & 15)) return OD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    unsigned long long* seg_keys = (unsigned long long*)workspace;
-    int* seg_count = (int*)((char*)workspace + lay.keys_bytes);
+    unsigned long long* keys = (unsigned long long*)workspace;
+    unsigned int* key_count = (unsigned int*)((char*)workspace + lay.keys_bytes);
 
     FilterParams fp;
     SelectParams sp;
@@ -424,7 +515,10 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
     fp.num_classes = num_classes;
     fp.has_ctr = bbox_ctrness ? 1 : 0;
     fp.total_chunks = lay.total_chunks;
-    for (int l = 0; l <= OD_MAX_LEVELS; ++l) { fp.chunk_start[l] = lay.chunk_start[l]; sp.chunk_start[l] = lay.chunk_start[l]; }
+    for (int l = 0; l <= OD_MAX_LEVELS; ++l) fp.chunk_start[l] = lay.chunk_start[l];
+    for (int l = 0; l < OD_MAX_LEVELS; ++l) { fp.key_off[l] = lay.key_off[l]; sp.key_off[l] = lay.key_off[l]; }
+    fp.keys_per_image = lay.keys_per_image;
+    sp.keys_per_image = lay.keys_per_image;
     for (int l = 0; l < OD_MAX_LEVELS; ++l) {
         const bool on = l < num_levels;
         fp.level_elems[l] = on ? level_size[l] * (long long)num_classes : 0;
@@ -475,16 +569,16 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
     sp.coder = coder;
     sp.clip = bbox_xform_clip;
 
+    OD_HIP(hipMemsetAsync(key_count, 0, lay.counts_bytes, s));
     if (lay.total_chunks > 0) {
         OD_LAUNCH(OD_KERNEL_FILTER, s,
                   hipLaunchKernelGGL(filter_kernel, dim3((unsigned)lay.total_chunks, (unsigned)batch), dim3(ST), 0, s,
-                                     fp, seg_keys, seg_count));
+                                     fp, keys, key_count));
     }
     OD_LAUNCH(OD_KERNEL_SELECT, s,
               hipLaunchKernelGGL(select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, sp,
-                                 (int)num_levels, lay.total_chunks, (const unsigned long long*)seg_keys,
-                                 (const int*)seg_count, image_hw, cand_boxes, cand_scores, cand_labels,
-                                 (long long*)cand_index, cand_count));
+                                 (int)num_levels, (const unsigned long long*)keys, (const unsigned int*)key_count,
+                                 image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count));
     return OD_OK;
 }
 

@@ -87,8 +87,22 @@ def make_targets(cfg: PipelineConfig, empty_image: int = -1) -> List[dict]:
     return out
 
 
-def make_head_outputs(cfg: PipelineConfig, images: Sequence[int] = None, with_ctrness: bool = False):
+# Classification-logit distributions for the synthetic head outputs: (mean, std, fraction saturated at +20).
+#   "stress": about half of all logits pass score_thresh = 0.05, far more than any trained detector emits;
+#             the parity tests use it because every level then overflows topk_candidates and ties abound.
+#   "prior":  centred on the bias the reference's classification head starts from, -log((1 - 0.01) / 0.01)
+#             (torchvision RetinaNetClassificationHead prior_probability = 0.01), with enough spread that
+#             about 1.4 % of the logits pass 0.05: the three finest levels still overflow topk_candidates.
+LOGIT_DISTRIBUTIONS = {
+    "stress": (-3.0, 1.5, 1e-3),
+    "prior": (-math.log(99.0), 0.75, 1e-4),
+}
+
+
+def make_head_outputs(cfg: PipelineConfig, images: Sequence[int] = None, with_ctrness: bool = False,
+                      logits: str = "stress"):
     """cls_logits [B, N, C] and bbox_regression [B, N, 4] (and bbox_ctrness [B, N, 1]) on the CPU."""
+    mean, std, hot_frac = LOGIT_DISTRIBUTIONS[logits]
     n, c = cfg.num_anchors, cfg.num_classes
     images = list(range(cfg.batch)) if images is None else list(images)
     cls = torch.empty((len(images), n, c), dtype=torch.float32)
@@ -96,8 +110,8 @@ def make_head_outputs(cfg: PipelineConfig, images: Sequence[int] = None, with_ct
     ctr = torch.empty((len(images), n, 1), dtype=torch.float32) if with_ctrness else None
     for i, b in enumerate(images):
         gen = torch.Generator().manual_seed(1000 * cfg.cfg_id + b + 500)
-        cls[i].normal_(-3.0, 1.5, generator=gen)
-        hot = torch.rand((n, c), generator=gen) < 1e-3
+        cls[i].normal_(mean, std, generator=gen)
+        hot = torch.rand((n, c), generator=gen) < hot_frac
         cls[i][hot] = 20.0
         reg[i].normal_(0.0, 0.5, generator=gen)
         big = torch.rand((n, 2), generator=gen) < 1e-4
