@@ -126,25 +126,21 @@ def main():
     anchors_per_image = [anchors_flat] * cfg.batch
     split_anchors = [anchors_l] * cfg.batch
 
+    from object_detection_amd.retinanet import postprocess_batched
+
     def step():
+        # Both halves are enqueued back to back; the one host synchronisation of a step is the read of the
+        # detection counts (which the list-of-dicts API of postprocess_detections needs) at its end.
+        ob, os_, ol, oc = postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
+                                              model.score_thresh, model.topk_candidates, model.nms_thresh,
+                                              model.detections_per_img, _C.CODER_BOXCODER,
+                                              model.box_coder.bbox_xform_clip, return_padded=True)
         matched = model.match_anchors(targets, anchors_per_image)
-        ob, os_, ol, oc = model_postprocess()
         if world > 1:
             packed = sharding.pack_detections(ob, os_, ol)
             sharding.all_gather_detections(packed, oc)
+        oc.tolist()
         return matched, oc
-
-    from object_detection_amd.retinanet import postprocess_batched
-
-    def model_postprocess():
-        # model.postprocess_detections without the final per-image slicing; the device->host read of
-        # the counts (which the list-of-dicts API needs) is kept so that every step is complete
-        out = postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
-                                  model.score_thresh, model.topk_candidates, model.nms_thresh,
-                                  model.detections_per_img, _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip,
-                                  return_padded=True)
-        out[3].tolist()
-        return out
 
     def sync():
         torch.cuda.synchronize(dev)

@@ -166,4 +166,88 @@ __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2
     return (x2 - x1) * (y2 - y1);
 }
 
+// ---- block-wide bitonic sort of 64-bit keys in LDS, descending --------------------------------------
+// For a workgroup of NT threads (NT = 1024 in the callers) and n_pad = power of two, 64 <= n_pad <= 8 * NT.
+// Thread t keeps the E = max(1, n_pad / NT) consecutive elements [t*E, t*E + E) in registers.  A stage of
+// stride j runs inside the registers (j < E), through lane shuffles (E <= j < 64 E, partners in the same
+// wave) or through LDS (partners in another wave); only the last kind needs barriers: 10 LDS stages for
+// n_pad = 1024 or 4096 instead of 55 or 78.  Keys must be in s[0, n_pad) and visible (barrier) on entry;
+// on return they are sorted and visible to all threads.
+template <int E, int NT>
+__device__ __forceinline__ void bitonic_sort_desc_impl(unsigned long long* s, int n_pad) {
+    const int tid = threadIdx.x;
+    const int active = n_pad / E;
+    const bool on = tid < active;                 // whole waves: n_pad >= 64
+    const int base = tid * E;
+    constexpr int WSPAN = 64 * E;                 // elements held by one wave
+    unsigned long long v[E];
+    bool in_regs = false;
+    for (int k = 2; k <= n_pad; k <<= 1) {
+        int j = k >> 1;
+        if (j >= WSPAN) {
+            if (in_regs && on) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) s[base + e] = v[e];
+            }
+            in_regs = false;
+            __syncthreads();
+            for (; j >= WSPAN; j >>= 1) {
+                const int pairs = n_pad >> 1;
+                for (int pr = tid; pr < pairs; pr += NT) {
+                    const int lo = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));   // insert a 0 bit at log2(j)
+                    const unsigned long long x = s[lo], y = s[lo | j];
+                    const bool desc = (lo & k) == 0;
+                    if ((x < y) == desc) { s[lo] = y; s[lo | j] = x; }
+                }
+                __syncthreads();
+            }
+        }
+        if (!in_regs && on) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) v[e] = s[base + e];
+        }
+        in_regs = true;
+        if (on) {
+            for (; j >= E; j >>= 1) {             // partners in another lane of the wave
+                const int lx = j / E;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = base + e;
+                    const unsigned long long o = __shfl_xor(v[e], lx);
+                    const bool keep_larger = ((i & j) == 0) == ((i & k) == 0);
+                    const bool o_larger = o > v[e];
+                    v[e] = (o_larger == keep_larger) ? o : v[e];
+                }
+            }
+#pragma unroll
+            for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // partners in this thread's registers
+                if (jj <= (k >> 1)) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if ((e & jj) == 0) {
+                            const bool desc = ((base + e) & k) == 0;
+                            const unsigned long long x = v[e], y = v[e | jj];
+                            if ((x < y) == desc) { v[e] = y; v[e | jj] = x; }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[base + e] = v[e];
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__device__ __forceinline__ void block_bitonic_sort_desc(unsigned long long* s, int n_pad) {
+    const int e = n_pad / NT;
+    if (e <= 1) bitonic_sort_desc_impl<1, NT>(s, n_pad);
+    else if (e == 2) bitonic_sort_desc_impl<2, NT>(s, n_pad);
+    else if (e == 4) bitonic_sort_desc_impl<4, NT>(s, n_pad);
+    else bitonic_sort_desc_impl<8, NT>(s, n_pad);
+}
+
 }  // namespace od

@@ -13,11 +13,12 @@
 // array with one global atomic, and copies them there, so the array is dense (its order is irrelevant:
 // keys are unique and get sorted).
 //
-// Kernel 2 (select_kernel, one 1024-thread workgroup per (image, level)): if all keys fit in LDS they are
-// read once, histogrammed on the fly, cut at the K-th key by one 4096-bin radix step inside LDS, and the
-// few keys above the cut are bitonic-sorted.  Otherwise the radix descent runs over the dense global array
-// (one coalesced pass per 12 bits) until the keys above the cut fit.  The first K sorted keys are decoded
-// and clipped straight into the padded candidate arrays.
+// Kernel 2 (select_kernel, one 1024-thread workgroup per (image, level)): a radix descent on the key,
+// 12 bits per step with a 4096-bin LDS histogram, narrows the interval that holds the K-th best key.  While
+// more than 8192 keys are at or above the cut the steps stream the dense global array (coalesced); then
+// the keys move into LDS and the descent continues there, compacting in place, until about K keys are
+// left.  Those are bitonic-sorted (registers + lane shuffles + LDS), and the first K are decoded and
+// clipped straight into the padded candidate arrays.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -29,7 +30,6 @@ constexpr int ST = 256;            // filter workgroup
 constexpr int CHUNK = 8192;        // logits per filter workgroup (32 KB)
 constexpr int SEL_T = 1024;        // select workgroup
 constexpr int CAP = 8192;          // keys held in LDS by the select kernel
-constexpr int CAP2 = 2048;         // keys above the radix cut that are sorted separately
 constexpr int HBITS = 12;
 constexpr int HBINS = 1 << HBITS;  // histogram bins per radix level
 constexpr int CSTRIDE = 64;        // one key counter per 256 bytes: atomics on one cache line serialise
@@ -221,6 +221,27 @@ __device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb,
     __syncthreads();
 }
 
+// Streams keys[0, total) through f(key) with 16 independent 16-byte loads per thread in flight: one
+// workgroup reads the whole array, so its rate is (bytes in flight) / (memory latency).
+// `keys` is 16-byte aligned; slots past `total` are passed as 0 (no valid key is 0).
+template <typename F>
+__device__ __forceinline__ void stream_keys(const unsigned long long* __restrict__ keys, unsigned int total, F f) {
+    constexpr int U = 16;
+    const ulonglong2* kv = reinterpret_cast<const ulonglong2*>(keys);
+    const unsigned int nvec = (total + 1) >> 1;
+    for (unsigned int v0 = 0; v0 < nvec; v0 += SEL_T * U) {
+        ulonglong2 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned int v = v0 + u * SEL_T + threadIdx.x;
+            k[u] = v < nvec ? kv[v] : make_ulonglong2(0ull, 0ull);
+            if (2 * v + 1 >= total) k[u].y = 0ull;             // odd tail: the slot after the last key is not ours
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { f(k[u].x); f(k[u].y); }
+    }
+}
+
 // wave-aggregated append of `k` (where take) to dst[*counter ...), capacity cap
 __device__ __forceinline__ void lds_append(bool take, unsigned long long k, unsigned long long* dst, int* counter, int cap) {
     const int lane = threadIdx.x & 63;
@@ -283,11 +304,18 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
                                                        long long* __restrict__ cand_index,
                                                        int* __restrict__ cand_count) {
     __shared__ unsigned long long s_keys[CAP];
-    __shared__ unsigned long long s_sel[CAP2];
     __shared__ unsigned int s_hist[HBINS];
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y;
+#ifdef OD_STAMPS
+    unsigned long long st[8];
+    int sti = 0;
+#define SSTAMP() st[sti++] = wall_clock64()
+#else
+#define SSTAMP()
+#endif
+    SSTAMP();
     const unsigned int total = key_count[(long long)(b * num_levels + l) * CSTRIDE];
     const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     const int K = p.topk;
@@ -295,54 +323,23 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
         if (tid == 0) cand_count[b * num_levels + l] = 0;
         return;
     }
-    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
-    if (tid == 0) { s_tmp[20] = 0; s_tmp[21] = 0; }
+    if (tid == 0) s_tmp[20] = 0;
     __syncthreads();
 
-    unsigned long long* sorted = s_keys;       // where the keys to sort end up
+    // ---- phase 1: bring the keys that can still be among the best K into LDS ---------------------------
+    // invariant: the K-th best key lies in [lo, lo + 2^w); `need` of the wanted keys lie inside that
+    // interval, the other K - need are above it
+    unsigned long long lo = p.lo0;
+    int w = p.w0;
+    int need = K;
     int cnt;
     if (total <= (unsigned int)CAP) {
-        // ---- everything fits: one pass over the keys, histogram of the first radix digit on the fly ------
-        const int d = p.w0 < HBITS ? p.w0 : HBITS;
-        const int shift = p.w0 - d;
-        const bool cut = (int)total > K && (int)total > CAP2 / 2;
-        for (int i = tid; i < (int)total; i += SEL_T) {
-            const unsigned long long k = keys[i];
-            s_keys[i] = k;
-            if (cut) {
-                unsigned long long bin = (k - p.lo0) >> shift;    // keys lie in [lo0, lo0 + 2^w0)
-                if (bin > (unsigned long long)(HBINS - 1)) bin = HBINS - 1;
-                atomicAdd(&s_hist[(unsigned int)bin], 1u);
-            }
-        }
-        __syncthreads();
+        for (int i = tid; i < (int)total; i += SEL_T) s_keys[i] = keys[i];
         cnt = (int)total;
-        if (cut) {
-            find_cut_bin(s_hist, 1 << d, K, s_tmp);
-            const int bstar = s_tmp[16], n_ge = s_tmp[17] + s_tmp[18];
-            if (n_ge <= CAP2) {                                    // else: too many equal digits, sort everything
-                for (int i0 = 0; i0 < cnt; i0 += SEL_T) {
-                    const int i = i0 + tid;
-                    unsigned long long k = 0;
-                    bool take = false;
-                    if (i < cnt) {
-                        k = s_keys[i];
-                        unsigned long long bin = (k - p.lo0) >> shift;
-                        if (bin > (unsigned long long)(HBINS - 1)) bin = HBINS - 1;
-                        take = (int)bin >= bstar;
-                    }
-                    lds_append(take, k, s_sel, &s_tmp[20], CAP2);
-                }
-                __syncthreads();
-                cnt = n_ge;
-                sorted = s_sel;
-            }
-        }
+        __syncthreads();
     } else {
-        // ---- radix descent over the dense global key array until the keys above the cut fit in LDS -------
-        unsigned long long lo = p.lo0;
-        int w = p.w0;
-        int need = K;            // how many of the keys inside [lo, lo + 2^w) are still wanted
+        // radix descent over the dense global key array (12 bits per coalesced pass) until the keys at or
+        // above the cut fit in LDS
         while (true) {
             const int d = w < HBITS ? w : HBITS;
             const int shift = w - d;
@@ -350,14 +347,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             for (int i = tid; i < nb; i += SEL_T) s_hist[i] = 0;
             __syncthreads();
             const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
-            for (unsigned int i0 = 0; i0 < total; i0 += SEL_T * 4) {       // 4 independent loads per thread
-                unsigned long long k[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const unsigned int i = i0 + u * SEL_T + tid; k[u] = i < total ? keys[i] : 0ull; }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
-            }
+            stream_keys(keys, total, [&](unsigned long long k) {
+                if (k >= lo && (k - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k - lo) >> shift)], 1u);
+            });
             __syncthreads();
             find_cut_bin(s_hist, nb, need, s_tmp);
             const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18];
@@ -368,51 +360,67 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             need -= above;
             if (n_ge <= CAP || w == 0) break;
         }
-        for (unsigned int i0 = 0; i0 < total; i0 += SEL_T * 4) {
-            unsigned long long k[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const unsigned int i = i0 + u * SEL_T + tid; k[u] = i < total ? keys[i] : 0ull; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) lds_append(k[u] >= lo && k[u] != 0ull, k[u], s_keys, &s_tmp[20], CAP);
-        }
+        SSTAMP();
+        stream_keys(keys, total, [&](unsigned long long k) { lds_append(k >= lo && k != 0ull, k, s_keys, &s_tmp[20], CAP); });
         __syncthreads();
         cnt = s_tmp[20];
         if (cnt > CAP) cnt = CAP;   // unreachable for unique keys; keeps LDS accesses in bounds
+        __syncthreads();            // s_tmp[20] is reused below
     }
 
+    SSTAMP();
+    // ---- phase 2: radix refinement inside LDS until about K keys remain (the sort costs n log^2 n) ------
+    int target = 64;
+    while (target < K) target <<= 1;             // sorting fewer than this many keys gains nothing
+    while (cnt > target && w > 0) {
+        const int d = w < HBITS ? w : HBITS;
+        const int shift = w - d;
+        const int nb = 1 << d;
+        for (int i = tid; i < nb; i += SEL_T) s_hist[i] = 0;
+        if (tid == 0) s_tmp[20] = 0;
+        __syncthreads();
+        const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
+        unsigned long long k[CAP / SEL_T];
+#pragma unroll
+        for (int u = 0; u < CAP / SEL_T; ++u) {
+            const int i = u * SEL_T + tid;
+            k[u] = i < cnt ? s_keys[i] : 0ull;
+            if (i < cnt && k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
+        }
+        __syncthreads();
+        find_cut_bin(s_hist, nb, need, s_tmp);
+        const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18];
+        lo = lo + ((unsigned long long)bstar << shift);
+        w = shift;
+        const int n_ge = (K - need) + above + h;
+        need -= above;
+        // compact in place: every thread holds its keys in registers, so the buffer can be rewritten
+#pragma unroll
+        for (int u = 0; u < CAP / SEL_T; ++u) lds_append(k[u] >= lo && k[u] != 0ull, k[u], s_keys, &s_tmp[20], CAP);
+        __syncthreads();
+        cnt = n_ge;
+    }
+    unsigned long long* sorted = s_keys;
+
+    SSTAMP();
     int n_pad = 64;
     while (n_pad < cnt) n_pad <<= 1;
     for (int i = cnt + tid; i < n_pad; i += SEL_T) sorted[i] = 0ull;
     __syncthreads();
 
-    // ---- bitonic sort, descending; each thread loads all its pairs of a stage, then stores ---------------
-    constexpr int PQ = CAP / 2 / SEL_T;
-    for (int k = 2; k <= n_pad; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            unsigned long long x[PQ], y[PQ];
-            int lo_i[PQ];
-#pragma unroll
-            for (int q = 0; q < PQ; ++q) {
-                const int pr = tid + q * SEL_T;                           // pair index
-                lo_i[q] = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));        // insert a 0 bit at log2(j)
-                const bool on = pr < (n_pad >> 1);
-                x[q] = on ? sorted[lo_i[q]] : 0ull;
-                y[q] = on ? sorted[lo_i[q] | j] : 0ull;
-            }
-#pragma unroll
-            for (int q = 0; q < PQ; ++q) {
-                const int pr = tid + q * SEL_T;
-                const bool desc = (lo_i[q] & k) == 0;
-                if (pr < (n_pad >> 1) && ((x[q] < y[q]) == desc)) { sorted[lo_i[q]] = y[q]; sorted[lo_i[q] | j] = x[q]; }
-            }
-            __syncthreads();
-        }
-    }
+    block_bitonic_sort_desc<SEL_T>(sorted, n_pad);
 
+    SSTAMP();
     const int n_out = cnt < K ? cnt : K;
     for (int r = tid; r < n_out; r += SEL_T)
         decode_store(p, l, b, sorted[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
     if (tid == 0) cand_count[b * num_levels + l] = n_out;
+#ifdef OD_STAMPS
+    SSTAMP();
+    if (tid == 0 && b == 1)
+        printf("select l %d total %u cnt %d n_pad %d: stamps %llu %llu %llu %llu %llu (x10ns)\n", l, total, cnt, n_pad,
+               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], sti > 5 ? st[5] - st[4] : 0ull);
+#endif
 }
 
 __global__ __launch_bounds__(256) void decode_kernel(const float4* __restrict__ rel, const float4* __restrict__ boxes,

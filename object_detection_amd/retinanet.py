@@ -128,6 +128,8 @@ def _shared_levels(anchors: List[List[Tensor]]) -> Optional[List[Tensor]]:
     """Per-level anchors if every image uses the same tensors (what AnchorGenerator hands out)."""
     first = anchors[0]
     for other in anchors[1:]:
+        if other is first:          # AnchorGenerator returns the same list object for every image
+            continue
         for a, b in zip(first, other):
             if a.data_ptr() != b.data_ptr() or a.shape != b.shape:
                 return None
@@ -199,7 +201,8 @@ class RetinaNet(nn.Module):
         pm = self.proposal_matcher
         gts = [t["boxes"] for t in targets]
         if isinstance(pm, det_utils.Matcher):
-            same = all(a.data_ptr() == anchors[0].data_ptr() and a.shape == anchors[0].shape for a in anchors)
+            first = anchors[0]
+            same = all(a is first or (a.data_ptr() == first.data_ptr() and a.shape == first.shape) for a in anchors)
             anc = anchors[0] if same else torch.stack(list(anchors))
             matched = kernels.match_retinanet(anc, gts, pm.high_threshold, pm.low_threshold,
                                               pm.allow_low_quality_matches)

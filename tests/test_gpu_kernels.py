@@ -221,3 +221,62 @@ def test_select_candidates(device, coder):
             bx = tv.clip_boxes_to_image(bx, shapes[b])
             assert torch.equal(cb[b, sl], bx), (b, l)
     assert int(cc[:, 0].min()) == K   # the finest level saturates top-k (ties at score 1.0 included)
+
+
+def _check_select_single_level(device, logits, C, thr, K):
+    """One level, batch of logits [B, N, C]: indices and scores of the top-k against the scalar checker."""
+    B, N = logits.shape[0], logits.shape[1]
+    reg = torch.zeros((B, N, 4))
+    anchors = torch.tensor([[0., 0., 8., 8.]]).repeat(N, 1)
+    hw = torch.tensor([[64, 64]] * B, dtype=torch.int32, device=device)
+    cb, cs, cl, ci, cc = kernels.select_candidates([logits.to(device)], [reg.to(device)], [anchors.to(device)], hw, thr, K,
+                                                   _C.CODER_BOXCODER, math.log(1000.0 / 16), want_index=True)
+    cs, ci, cc = cs.cpu(), ci.cpu(), cc.cpu()
+    for b in range(B):
+        s_ref, i_ref = c_oracle.filter_topk(logits[b].numpy(), None, C, thr, K)
+        n = int(cc[b, 0])
+        assert n == len(s_ref), (b, n, len(s_ref))
+        assert np.array_equal(ci[b, :n].numpy(), i_ref), b
+        assert np.array_equal(cs[b, :n].numpy().view(np.uint32), s_ref.view(np.uint32)), b
+
+
+def test_select_ties_beyond_lds_capacity(device):
+    """More candidates than fit in LDS, and the K-th best lies inside a run of thousands of equal scores:
+    the radix descent has to go all the way down to the index bits (tie rule: lower flat index first)."""
+    gen = torch.Generator().manual_seed(7)
+    N, C = 30011, 3                                      # N*C is odd: exercises the unaligned chunk tail
+    logits = torch.empty((2, N, C)).normal_(-1.0, 1.0, generator=gen)
+    tie = torch.rand((2, N, C), generator=gen) < 0.3     # ~27k logits with one identical value above the rest
+    logits[tie] = 6.0
+    logits[1][torch.rand((N, C), generator=gen) < 0.001] = 30.0   # a few saturated scores on top (image 1)
+    for K in (1000, 4096):
+        _check_select_single_level(device, logits, C, 0.5, K)
+
+
+def test_select_all_equal_and_no_threshold(device):
+    """Every score identical (order = flat index), and score_thresh <= 0 (nothing is prefiltered)."""
+    logits = torch.full((1, 5000, 2), 0.25)
+    _check_select_single_level(device, logits, 2, 0.05, 1000)      # 10000 equal candidates > LDS capacity
+    _check_select_single_level(device, logits[:, :3000], 2, 0.05, 1000)   # 6000 equal candidates, all in LDS
+    gen = torch.Generator().manual_seed(11)
+    small = torch.empty((2, 777, 3)).normal_(0.0, 3.0, generator=gen)
+    _check_select_single_level(device, small, 3, 0.0, 300)
+    _check_select_single_level(device, small, 3, -1.0, 4096)   # every element passes, K above the count
+
+
+def test_match_retinanet_heavy_entry_overflow(device):
+    """GT boxes that cover almost the whole image meet every anchor tile: the per-GT entry budget of the
+    cooperative path overflows and the restore step falls back to re-examining the tiles."""
+    cfg = synthetic.CFG2
+    ag, anchors = _anchors_cpu(cfg.image_size, cfg.grids[1:], synthetic.retinanet_anchor_sizes(6)[1:])   # 196,560 anchors
+    gen = torch.Generator().manual_seed(3)
+    m = 30
+    lo = torch.rand((m, 2), generator=gen) * 40.0
+    hi = 1024.0 - torch.rand((m, 2), generator=gen) * 40.0
+    big = torch.cat([lo, hi], dim=1)
+    small = synthetic.make_gt_boxes(10, cfg.image_size, gen)
+    gts = [torch.cat([big, small]), big[:26].clone()]
+    out = kernels.match_retinanet(anchors.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+    for b, g in enumerate(gts):
+        ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, True)
+        assert np.array_equal(out[b].numpy(), ref), f"image {b}"

@@ -1,0 +1,63 @@
+"""How much of a bench step is host (Python / launch) time?  Times the cfg2 step with and without the
+per-step host synchronisation and prints a cProfile of the enqueue path."""
+import cProfile
+import os
+import pstats
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from object_detection_amd import _C, synthetic  # noqa: E402
+from object_detection_amd.retinanet import postprocess_batched  # noqa: E402
+from object_detection_amd.retinanet_model import get_model  # noqa: E402
+
+dev = torch.device("cuda:0")
+cfg = synthetic.CFG2
+L = len(cfg.grids)
+model = get_model(cfg.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
+                  score_thresh=cfg.score_thresh, nms_thresh=cfg.nms_thresh, topk_candidates=cfg.topk_candidates,
+                  detections_per_img=cfg.detections_per_img, fg_iou_thresh=cfg.fg_iou_thresh,
+                  bg_iou_thresh=cfg.bg_iou_thresh, min_size=1024, max_size=1024).to(dev).eval()
+sizes = synthetic.level_sizes(cfg)
+grids = [(g, g) for g in cfg.grids]
+strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
+anchors_l = model.anchor_generator.grid_anchors(grids, strides, dev)
+anchors_flat = torch.cat(anchors_l)
+head = {k: v.to(dev) for k, v in synthetic.make_head_outputs(cfg).items()}
+targets = [{k: v.to(dev) for k, v in t.items()} for t in synthetic.make_targets(cfg, empty_image=cfg.batch - 1)]
+split = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+shapes = [cfg.image_size] * cfg.batch
+apl = [anchors_flat] * cfg.batch
+sal = [anchors_l] * cfg.batch
+
+
+def enqueue():
+    out = postprocess_batched(split["cls_logits"], split["bbox_regression"], sal, shapes, model.score_thresh,
+                              model.topk_candidates, model.nms_thresh, model.detections_per_img, _C.CODER_BOXCODER,
+                              model.box_coder.bbox_xform_clip, return_padded=True)
+    model.match_anchors(targets, apl)
+    return out
+
+
+def timed(fn, n=200):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e6
+
+
+print("step with per-step sync  : %.1f us" % timed(lambda: enqueue()[3].tolist()))
+print("steps enqueued back to back: %.1f us" % timed(enqueue))
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(200):
+    enqueue()
+pr.disable()
+torch.cuda.synchronize()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
