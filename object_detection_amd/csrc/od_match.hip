@@ -51,7 +51,9 @@ constexpr int HCAP_PER_GT = 160;  // heavy-entry buffer capacity = HCAP_PER_GT *
 
 struct MatchWs {                 // workspace carve-up (all device pointers)
     uint32_t* gt_max_key;        // [m_total * GSTRIDE] ordered-key maximum IoU of every GT row, one per GSTRIDE words
-    int* argmax;                 // [batch, n]         per-anchor argmax before thresholding
+    void* argmax;                // [batch, n]         per-anchor argmax before thresholding: uint16 when every GT
+                                 //                    index fits (halves this write stream), else int32
+    int argmax16;
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
     uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT << 9 | several << 8 | local anchor, y = value key
     int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
@@ -66,6 +68,14 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
 };
 
 constexpr uint32_t kZeroKey = 0x80000000u;           // ordered_key(+0.0f), the initial per-GT maximum
+
+__device__ __forceinline__ void put_argmax(const MatchWs& ws, long long i, int g) {
+    if (ws.argmax16) reinterpret_cast<unsigned short*>(ws.argmax)[i] = (unsigned short)g;
+    else reinterpret_cast<int*>(ws.argmax)[i] = g;
+}
+__device__ __forceinline__ int get_argmax(const MatchWs& ws, long long i) {
+    return ws.argmax16 ? (int)reinterpret_cast<const unsigned short*>(ws.argmax)[i] : reinterpret_cast<const int*>(ws.argmax)[i];
+}
 
 // heavy-entry slots of an image: proportional to its own GT count, so that images cannot starve each other
 __device__ __forceinline__ long long entry_base(int b, int m0) { return (long long)HCAP_PER_GT * m0 + 256ll * b; }
@@ -101,6 +111,26 @@ __device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __rest
 // memory operations it issues (atomics) are younger than those loads and never delay them.  `cur` is the
 // value of gmax[m0 + g0 + lane] read one chunk earlier (a lower bound of the row maximum, which only
 // grows): a wave whose own maximum does not exceed it can skip its atomic.
+__device__ __forceinline__ bool overlaps_tile(const WaveTile& t, const float4& gb) {
+    return !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
+}
+
+// Hands the GT marked in `mask` (lane j holds GT g0 + j in gb) to f in ascending order; see below.
+template <typename F>
+__device__ __forceinline__ void visit_survivors(unsigned long long mask, const float4& gb, int g0, int& rank, int share,
+                                                int nshare, F f) {
+    const float ga = box_area(gb.x, gb.y, gb.z, gb.w);
+    while (mask) {
+        const int j = __ffsll(mask) - 1;
+        mask &= mask - 1;
+        const bool mine = (nshare == 1) || (rank % nshare == share);
+        if (mine)
+            f(g0 + j, j, rank, bcast_lane(gb.x, j), bcast_lane(gb.y, j), bcast_lane(gb.z, j), bcast_lane(gb.w, j),
+              bcast_lane(ga, j));
+        ++rank;
+    }
+}
+
 template <typename F, typename D>
 __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const float4* __restrict__ gt, int m0,
                                                         const uint32_t* gmax, int g_begin, int g_end, int share,
@@ -121,18 +151,8 @@ __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const
             nxt = gt[m0 + gn];
             if (gmax) nxt_max = gmax[(long long)(m0 + gn) * GSTRIDE];
         }
-        const bool ok = (g0 + lane < g_end) && !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
-        const float ga = box_area(gb.x, gb.y, gb.z, gb.w);
-        unsigned long long mask = __ballot(ok);
-        while (mask) {
-            const int j = __ffsll(mask) - 1;
-            mask &= mask - 1;
-            const bool mine = (nshare == 1) || (rank % nshare == share);
-            if (mine)
-                f(g0 + j, j, rank, bcast_lane(gb.x, j), bcast_lane(gb.y, j), bcast_lane(gb.z, j), bcast_lane(gb.w, j),
-                  bcast_lane(ga, j));
-            ++rank;
-        }
+        const bool ok = (g0 + lane < g_end) && overlaps_tile(t, gb);
+        visit_survivors(__ballot(ok), gb, g0, rank, share, nshare, f);
         chunk_done(g0, cur);
     }
 }
@@ -208,18 +228,30 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         return;
     }
 
+    // up to two GT chunks are requested together with the anchors and stay in registers: one memory round
+    // trip for the whole tile instead of one per pass and chunk
+    constexpr int RESIDENT = 128;
+    float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA;
+    if (M <= RESIDENT) {
+        if (lane < M) gA = gt[m0 + lane];
+        if (64 + lane < M) gB = gt[m0 + 64 + lane];
+    }
     WaveTile t;
     load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+    unsigned long long maskA = 0ull, maskB = 0ull;
+    if (M <= RESIDENT) {
+        maskA = __ballot(lane < M && overlaps_tile(t, gA));
+        maskB = __ballot(64 + lane < M && overlaps_tile(t, gB));
+    }
     if (M > HEAVY) {                                 // count the GT this tile meets; queue it if heavy
-        int cnt = 0;
-        for (int g0 = 0; g0 < M; g0 += 64) {
-            const int g = g0 + lane;
-            bool ok = g < M;
-            if (ok) {
-                const float4 gb = gt[m0 + g];
-                ok = !(gb.z <= t.bx1 || gb.x >= t.bx2 || gb.w <= t.by1 || gb.y >= t.by2);
+        int cnt = __popcll(maskA) + __popcll(maskB);
+        if (M > RESIDENT) {
+            for (int g0 = 0; g0 < M; g0 += 64) {
+                const int g = g0 + lane;
+                bool ok = g < M;
+                if (ok) ok = overlaps_tile(t, gt[m0 + g]);
+                cnt += __popcll(__ballot(ok));
             }
-            cnt += __popcll(__ballot(ok));
         }
         if (cnt > HEAVY) {
             if (lane == 0) {                       // queue slot + room for one entry per GT met, in one atomic
@@ -238,33 +270,42 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
     int lcount = 0;                                  // wave-uniform
     uint32_t kreg = 0u;                              // lane j: wave maximum of the IoU with GT g0 + j
 
-    for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1,
-        [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
-            uint32_t k;
-            const long long slot = (long long)lcount * ws.list_stride + wslot;
-            const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
-                                          [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
-                                              store_tie_masks(ws.wave_mask + slot * R, a0, a1, a2, a3);
-                                          });
-            if (want_restore && k > kZeroKey) {        // wave-uniform: this GT overlaps an anchor of the wave
-                kreg = (lane == j) ? k : kreg;
-                if (ent != 0xffffffffu) ws.wave_list[slot] = make_uint2(ent, k);
-                ++lcount;                              // <= HEAVY < LCAP for a light tile
-            }
-        },
-        [&](int g0, uint32_t cur) {
-            if (!want_restore) return;
-            if (kreg > cur) atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
-            kreg = 0u;
-        });
+    auto eval = [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+        uint32_t k;
+        const long long slot = (long long)lcount * ws.list_stride + wslot;
+        const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
+                                      [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
+                                          store_tie_masks(ws.wave_mask + slot * R, a0, a1, a2, a3);
+                                      });
+        if (want_restore && k > kZeroKey) {            // wave-uniform: this GT overlaps an anchor of the wave
+            kreg = (lane == j) ? k : kreg;
+            if (ent != 0xffffffffu) ws.wave_list[slot] = make_uint2(ent, k);
+            ++lcount;                                  // <= HEAVY = LCAP for a light tile
+        }
+    };
+    auto chunk_done = [&](int g0, uint32_t cur) {
+        if (!want_restore) return;
+        if (kreg > cur) atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
+        kreg = 0u;
+    };
+    if (M <= RESIDENT) {
+        int rank = 0;
+        visit_survivors(maskA, gA, 0, rank, 0, 1, eval);
+        chunk_done(0, 0u);
+        if (maskB) {
+            visit_survivors(maskB, gB, 64, rank, 0, 1, eval);
+            chunk_done(64, 0u);
+        }
+    } else {
+        for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, chunk_done);
+    }
 
-    int* amax = ws.argmax + (long long)b * n;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long long idx = base + r * 64 + lane;
         if (idx < n) {
             out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
-            if (want_restore) amax[idx] = bidx[r];
+            if (want_restore) put_argmax(ws, (long long)b * n + idx, bidx[r]);
         }
     }
     if (want_restore && lane == 0) ws.wave_cnt[wslot] = lcount;
@@ -340,7 +381,7 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
             const long long idx = base + threadIdx.x;
             if (idx < n) {
                 out[idx] = (bb < low) ? -1 : ((bb < high) ? -2 : (long long)bi);
-                if (want_restore) ws.argmax[(long long)b * n + idx] = bi;
+                if (want_restore) put_argmax(ws, (long long)b * n + idx, bi);
             }
         }
         __syncthreads();
@@ -399,7 +440,7 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long long idx = base + r * 64 + lane;
-        if (idx < n && restore[r]) matched[(long long)b * n + idx] = (long long)ws.argmax[(long long)b * n + idx];
+        if (idx < n && restore[r]) matched[(long long)b * n + idx] = (long long)get_argmax(ws, (long long)b * n + idx);
     }
 }
 
@@ -455,7 +496,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
             const uint32_t gm = ws.gt_max_key[(long long)(gt_offsets[b] + (int)(word >> 9)) * GSTRIDE];
             if (key == gm && !ws.image_flag[b]) {
                 long long* out = matched + (long long)b * n;
-                const int* amax = ws.argmax + (long long)b * n;
+                const long long abase = (long long)b * n;
                 const long long base = (long long)wt * WTILE;
                 if (word & 256u) {                       // several anchors of the tile tie: walk their masks
                     const unsigned long long* mp = (light ? ws.wave_mask : ws.heavy_mask) + (ebase + i) * R;
@@ -467,12 +508,12 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
                         while (mask[r]) {
                             const long long idx = base + r * 64 + (__ffsll(mask[r]) - 1);
                             mask[r] &= mask[r] - 1;
-                            if (idx < n) out[idx] = (long long)amax[idx];
+                            if (idx < n) out[idx] = (long long)get_argmax(ws, abase + idx);
                         }
                     }
                 } else {
                     const long long idx = base + (word & 255u);
-                    if (idx < n) out[idx] = (long long)amax[idx];
+                    if (idx < n) out[idx] = (long long)get_argmax(ws, abase + idx);
                 }
             }
         }
@@ -492,7 +533,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     const long long all_threads = (long long)gridDim.x * 256;
     for (int b = 0; b < batch; ++b) {
         if (!ws.image_flag[b] || gt_offsets[b + 1] - gt_offsets[b] <= 0) continue;
-        for (long long idx = tid; idx < n; idx += all_threads) matched[(long long)b * n + idx] = (long long)ws.argmax[(long long)b * n + idx];
+        for (long long idx = tid; idx < n; idx += all_threads) matched[(long long)b * n + idx] = (long long)get_argmax(ws, (long long)b * n + idx);
     }
 }
 
@@ -642,7 +683,8 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     MatchWs ws;
     char* w = (char*)workspace;
     ws.gt_max_key = (uint32_t*)(w + off[0]);
-    ws.argmax = (int*)(w + off[1]);
+    ws.argmax = (void*)(w + off[1]);
+    ws.argmax16 = m_total <= 65536 ? 1 : 0;
     ws.wave_cnt = (int*)(w + off[2]);
     ws.wave_list = (uint2*)(w + off[3]);
     ws.image_flag = (int*)(w + off[4]);
