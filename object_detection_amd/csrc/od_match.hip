@@ -59,7 +59,7 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
     int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
     unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
     int* any_flag;               // [1]                some image_flag is set
-    int2* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot) for the cooperative kernel
+    int4* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot, GT met, -) for the cooperative kernel
     uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = entry word, z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
     unsigned long long* wave_mask;   // [LCAP * batch * wtiles][R]  attaining-anchor masks of tie entries (same index as wave_list)
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
             if (lane == 0) {                       // queue slot + room for one entry per GT met, in one atomic
                 const unsigned long long old =
                     atomicAdd(ws.heavy_count + b * 16, (1ull << 32) | (unsigned long long)(want_restore ? cnt : 0));
-                ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int2(wt, (int)(uint32_t)old);
+                ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int4(wt, (int)(uint32_t)old, cnt, 0);
                 if (want_restore) ws.wave_cnt[wslot] = -2;
             }
             return;
@@ -323,15 +323,39 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
     constexpr int NW = HT / 64;
     __shared__ float s_best[NW][WTILE];
     __shared__ int s_bidx[NW][WTILE];
+    __shared__ int s_cost[HT];
+    __shared__ int s_pick;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
     const unsigned long long hc = ws.heavy_count[b * 16];
     const int nheavy = (int)(hc >> 32);
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     const bool entries_fit = (long long)(uint32_t)hc <= entry_cap(M);   // else the restore kernel redoes the image's heavy tiles
-    for (int item = blockIdx.x; item < nheavy; item += gridDim.x) {
-        const int2 qi = ws.heavy_queue[(long long)b * wtiles + item];
+    // Blocks are numbered image-fastest, so the hardware hands out "the r-th tile of every image" together.
+    // With r = rank by cost (GT met, descending) every CU receives a mix of expensive and cheap tiles
+    // instead of whatever the arrival order of the queue gives; done when the queue fits one pass.
+    const bool by_cost = nheavy <= HT;
+    if (by_cost) {
+        s_cost[threadIdx.x] = (int)threadIdx.x < nheavy ? ws.heavy_queue[(long long)b * wtiles + threadIdx.x].z : -1;
+        __syncthreads();
+    }
+    for (int item = blockIdx.y; item < nheavy; item += gridDim.y) {
+        int pick = item;
+        if (by_cost) {                               // the queue entry whose (cost desc, position asc) rank is `item`
+            if ((int)threadIdx.x < nheavy) {
+                const int mine = s_cost[threadIdx.x];
+                int rank = 0;
+                for (int i = 0; i < nheavy; ++i) {
+                    const int c = s_cost[i];
+                    rank += (c > mine || (c == mine && i < (int)threadIdx.x)) ? 1 : 0;
+                }
+                if (rank == item) s_pick = (int)threadIdx.x;
+            }
+            __syncthreads();
+            pick = s_pick;
+        }
+        const int4 qi = ws.heavy_queue[(long long)b * wtiles + pick];
         const int wt = qi.x;
         const long long wslot = (long long)b * wtiles + wt;
         const long long ebase = entry_base(b, m0) + qi.y;
@@ -649,7 +673,7 @@ static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t of
     off[4] = off[3] + align256(tiles * LCAP * sizeof(uint2));                       // image_flag
     off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // any_flag (256 B) + heavy_count
     off[6] = off[5] + 256 + (size_t)batch * 128;                                    // heavy_queue
-    off[7] = off[6] + align256(tiles * sizeof(int2));                               // heavy_entries
+    off[7] = off[6] + align256(tiles * sizeof(int4));                               // heavy_entries
     off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));            // wave_mask
     off[9] = off[8] + align256(tiles * LCAP * R * sizeof(unsigned long long));      // heavy_mask
     off[10] = off[9] + align256(heavy_capacity(m_total, batch) * R * sizeof(unsigned long long));
@@ -690,7 +714,7 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     ws.image_flag = (int*)(w + off[4]);
     ws.any_flag = (int*)(w + off[5]);
     ws.heavy_count = (unsigned long long*)(w + off[5] + 256);
-    ws.heavy_queue = (int2*)(w + off[6]);
+    ws.heavy_queue = (int4*)(w + off[6]);
     ws.heavy_entries = (uint4*)(w + off[7]);
     ws.wave_mask = (unsigned long long*)(w + off[8]);
     ws.heavy_mask = (unsigned long long*)(w + off[9]);
@@ -704,10 +728,10 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
                                  (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
                                  gt_offsets, ws, restore, high, low, (long long*)matched));
     if (m_total > HEAVY) {
-        int heavy_x = 4096 / batch > 64 ? 4096 / batch : 64;
-        if (heavy_x > wtiles) heavy_x = wtiles;
+        int heavy_y = 4096 / batch > 64 ? 4096 / batch : 64;
+        if (heavy_y > wtiles) heavy_y = wtiles;
         OD_LAUNCH(OD_KERNEL_MATCH_HEAVY, s,
-                  hipLaunchKernelGGL(match_heavy_kernel, dim3((unsigned)heavy_x, (unsigned)batch), dim3(HT), 0, s, (const float4*)anchors,
+                  hipLaunchKernelGGL(match_heavy_kernel, dim3((unsigned)batch, (unsigned)heavy_y), dim3(HT), 0, s, (const float4*)anchors,
                                      (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
                                      gt_offsets, ws, restore, high, low, (long long*)matched));
     }

@@ -77,16 +77,29 @@ __device__ __forceinline__ float score_of(const FilterParams& p, int l, int b, f
     return s;
 }
 
-// Every wave works on its own: it tests its 2048 logits against the prefilter bound, then scores the few
-// that remain one per lane and round (a single sigmoid site, operands picked from the register file by a
-// select tree), stages the survivors' keys in its LDS buffer, and appends them to the (image, level)
-// array with one global atomic per flush.
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// Every wave works on its own.  It tests its 2048 logits (in registers) against the prefilter bound and
+// writes the positions of the few that remain to a queue in LDS; the queue is then consumed 64 entries at
+// a time -- all lanes busy at a single sigmoid site, the logit re-read from the cache by position -- and
+// the survivors' keys are staged in LDS and appended to the (image, level) array with one global atomic
+// per flush.
 __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
                                                     unsigned int* __restrict__ key_count) {
     constexpr int WCAP = 256;                      // staged keys per wave
     constexpr int ITERS = CHUNK / (ST * 4);
-    static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
+    constexpr int WELEMS = CHUNK / (ST / 64);      // elements per wave
+    static_assert(ITERS == 8 && CHUNK <= 65536, "eight 16-byte loads per thread; positions fit 16 bits");
     __shared__ unsigned long long s_buf[ST / 64][WCAP];
+    __shared__ unsigned short s_queue[ST / 64][WELEMS];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
@@ -102,17 +115,14 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     const long long rem = E - e0;
     const int len = rem < CHUNK ? (int)rem : CHUNK;
 
-    // thread t owns elements it*1024 + t*4 + k, held in v<it>.<k>; all loads are requested before the first
-    // use: the kernel is a read-once stream and needs its bytes in flight.  (Named registers, no array: an
-    // array read through selects would be placed in scratch memory.)
+    // thread t owns elements it*1024 + t*4 + k; all loads are requested before the first use: the kernel is
+    // a read-once stream and needs its bytes in flight
     typedef float vec4f __attribute__((ext_vector_type(4)));
     vec4f v0, v1, v2, v3, v4, v5, v6, v7;
     if (vec_ok && len == CHUNK) {
         const vec4f* vp = reinterpret_cast<const vec4f*>(src + e0 + tid * 4);
-        v0 = __builtin_nontemporal_load(vp + 0 * ST); v1 = __builtin_nontemporal_load(vp + 1 * ST);
-        v2 = __builtin_nontemporal_load(vp + 2 * ST); v3 = __builtin_nontemporal_load(vp + 3 * ST);
-        v4 = __builtin_nontemporal_load(vp + 4 * ST); v5 = __builtin_nontemporal_load(vp + 5 * ST);
-        v6 = __builtin_nontemporal_load(vp + 6 * ST); v7 = __builtin_nontemporal_load(vp + 7 * ST);
+        v0 = vp[0 * ST]; v1 = vp[1 * ST]; v2 = vp[2 * ST]; v3 = vp[3 * ST];
+        v4 = vp[4 * ST]; v5 = vp[5 * ST]; v6 = vp[6 * ST]; v7 = vp[7 * ST];
     } else {
         auto ld4 = [&](int it) {
             vec4f r;
@@ -146,6 +156,24 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         pending &= in_range;
     }
 
+    // queue the positions (offsets inside the chunk) of the pending elements, lane after lane
+    const int mine = __popc(pending);
+    const int incl = wave_inclusive_sum(mine);
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) return;                        // nothing in this wave's 2048 logits can pass
+    unsigned short* queue = s_queue[wave];
+    {
+        int pos = incl - mine;
+        while (pending) {
+            const int e = __ffs(pending) - 1;
+            pending &= pending - 1u;
+            queue[pos++] = (unsigned short)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
     unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
     unsigned int* counter = key_count + ((long long)b * p.num_levels + l) * CSTRIDE;
     unsigned long long* buf = s_buf[wave];
@@ -158,29 +186,14 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         for (int i = lane; i < staged; i += 64) dst[base + i] = buf[i];
         staged = 0;
     };
-    while (__ballot(pending != 0u)) {
-        const bool active = pending != 0u;
-        const int e = active ? (__ffs(pending) - 1) : 0;
-        pending &= pending - 1u;
-        // xe = element e through a select tree (a dynamically indexed array would live in scratch memory)
-        const bool b0 = e & 1, b1 = e & 2;
-        const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
-        const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
-        const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
-        const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
-        const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
-        const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
-        const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
-        const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
-        const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
-        const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
-        const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
-        const float xe = b4 ? h1 : h0;
-        const long long flat = e0 + (e >> 2) * (ST * 4) + tid * 4 + (e & 3);
+    for (int i0 = 0; i0 < total; i0 += 64) {
+        const bool active = i0 + lane < total;
         float sc = 0.0f;
         bool pass = false;
+        long long flat = 0;
         if (active) {
-            sc = score_of(p, l, b, xe, flat);
+            flat = e0 + queue[i0 + lane];
+            sc = score_of(p, l, b, src[flat], flat);   // the logit was just streamed through the cache
             pass = sc > p.thresh;
         }
         const uint64_t bal = __ballot(pass);
@@ -308,14 +321,6 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y;
-#ifdef OD_STAMPS
-    unsigned long long st[8];
-    int sti = 0;
-#define SSTAMP() st[sti++] = wall_clock64()
-#else
-#define SSTAMP()
-#endif
-    SSTAMP();
     const unsigned int total = key_count[(long long)(b * num_levels + l) * CSTRIDE];
     const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     const int K = p.topk;
@@ -360,15 +365,13 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             need -= above;
             if (n_ge <= CAP || w == 0) break;
         }
-        SSTAMP();
-        stream_keys(keys, total, [&](unsigned long long k) { lds_append(k >= lo && k != 0ull, k, s_keys, &s_tmp[20], CAP); });
+            stream_keys(keys, total, [&](unsigned long long k) { lds_append(k >= lo && k != 0ull, k, s_keys, &s_tmp[20], CAP); });
         __syncthreads();
         cnt = s_tmp[20];
         if (cnt > CAP) cnt = CAP;   // unreachable for unique keys; keeps LDS accesses in bounds
         __syncthreads();            // s_tmp[20] is reused below
     }
 
-    SSTAMP();
     // ---- phase 2: radix refinement inside LDS until about K keys remain (the sort costs n log^2 n) ------
     int target = 64;
     while (target < K) target <<= 1;             // sorting fewer than this many keys gains nothing
@@ -402,7 +405,6 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
     }
     unsigned long long* sorted = s_keys;
 
-    SSTAMP();
     int n_pad = 64;
     while (n_pad < cnt) n_pad <<= 1;
     for (int i = cnt + tid; i < n_pad; i += SEL_T) sorted[i] = 0ull;
@@ -410,17 +412,10 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
 
     block_bitonic_sort_desc<SEL_T>(sorted, n_pad);
 
-    SSTAMP();
     const int n_out = cnt < K ? cnt : K;
     for (int r = tid; r < n_out; r += SEL_T)
         decode_store(p, l, b, sorted[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
     if (tid == 0) cand_count[b * num_levels + l] = n_out;
-#ifdef OD_STAMPS
-    SSTAMP();
-    if (tid == 0 && b == 1)
-        printf("select l %d total %u cnt %d n_pad %d: stamps %llu %llu %llu %llu %llu (x10ns)\n", l, total, cnt, n_pad,
-               st[1] - st[0], st[2] - st[1], st[3] - st[2], st[4] - st[3], sti > 5 ? st[5] - st[4] : 0ull);
-#endif
 }
 
 __global__ __launch_bounds__(256) void decode_kernel(const float4* __restrict__ rel, const float4* __restrict__ boxes,
