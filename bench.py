@@ -36,6 +36,19 @@ from object_detection_amd import _C, kernels, sharding, synthetic  # noqa: E402
 from object_detection_amd.retinanet_model import get_model  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+# HBM bytes per launch from the rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE; collected by tools/pmc_bench.sh in
+# separate profiler runs of this same script and committed): PMC counters cannot be read from inside the process.
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+
+
+def pmc_traffic(kernel: str):
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    entry = table.get(kernel + "_kernel")
+    return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
 def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
@@ -198,6 +211,21 @@ def main():
     sync()
     ms_host_sync = 1e3 * (time.perf_counter() - t1) / 20
 
+    # the two halves on their own (they never run in the same forward of the reference): 20 launches each
+    def half(fn):
+        sync()
+        th = time.perf_counter()
+        for _ in range(20):
+            fn()
+        sync()
+        return 1e3 * (time.perf_counter() - th) / 20
+
+    ms_post = half(lambda: postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
+                                               model.score_thresh, model.topk_candidates, model.nms_thresh,
+                                               model.detections_per_img, _C.CODER_BOXCODER,
+                                               model.box_coder.bbox_xform_clip, return_padded=True))
+    ms_match = half(lambda: model.match_anchors(targets, anchors_per_image))
+
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -223,6 +251,13 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_blocking_host_read": ms_host_sync,
             "detections_per_step": total_detections / args.steps,
+            "phases": {
+                "postprocess_ms": ms_post, "postprocess_images_per_s": cfg.batch / (ms_post * 1e-3),
+                "match_ms": ms_match, "match_images_per_s": cfg.batch / (ms_match * 1e-3),
+                # brute-force equivalent: every (anchor, GT) pair of the batch counts, although the kernels
+                # skip the pairs whose boxes cannot overlap
+                "match_pairs_per_s": cfg.batch * cfg.num_anchors * cfg.num_gt / (ms_match * 1e-3),
+            },
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -247,7 +282,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(dominant),
                 "launch_us": dur_s * 1e6,
                 "algorithmic_MB_per_launch": abytes / 1e6,
             },
