@@ -87,19 +87,21 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
     return v;
 }
 
-// Every wave works on its own.  It tests its 2048 logits (in registers) against the prefilter bound and
-// writes the positions of the few that remain to a queue in LDS; the queue is then consumed 64 entries at
-// a time -- all lanes busy at a single sigmoid site, the logit re-read from the cache by position -- and
-// the survivors' keys are staged in LDS and appended to the (image, level) array with one global atomic
-// per flush.
+// Every wave tests its 2048 logits (in registers) against the prefilter bound.  The workgroup reserves one
+// slot of the (image, level) key array per remaining logit with ONE global atomic -- issued before the
+// scoring, so that its round trip overlaps it; each wave moves its logits to a queue in LDS, scores the
+// queue 64 entries at a time at a single sigmoid site, and copies the keys out.  A queued logit that fails
+// the exact threshold leaves a zero key in its slot (rare: the prefilter bound is within 0.1 % of the
+// threshold); the select kernel ignores zero keys.  The kernel is a stream: everything a wave does after its
+// loads is kept free of further memory round trips, which under load cost as much as the loads themselves.
 __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
                                                     unsigned int* __restrict__ key_count) {
-    constexpr int WCAP = 256;                      // staged keys per wave
     constexpr int ITERS = CHUNK / (ST * 4);
-    constexpr int WELEMS = CHUNK / (ST / 64);      // elements per wave
-    static_assert(ITERS == 8 && CHUNK <= 65536, "eight 16-byte loads per thread; positions fit 16 bits");
-    __shared__ unsigned long long s_buf[ST / 64][WCAP];
-    __shared__ unsigned short s_queue[ST / 64][WELEMS];
+    constexpr int QCAP = 512;                      // queue entries per wave and pass
+    static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
+    __shared__ unsigned long long s_queue[ST / 64][QCAP];
+    __shared__ int s_tot[ST / 64];
+    __shared__ unsigned int s_base;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
@@ -115,8 +117,8 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     const long long rem = E - e0;
     const int len = rem < CHUNK ? (int)rem : CHUNK;
 
-    // thread t owns elements it*1024 + t*4 + k; all loads are requested before the first use: the kernel is
-    // a read-once stream and needs its bytes in flight
+    // thread t owns elements it*1024 + t*4 + k, held in v<it>.<k>; all loads are requested before the first
+    // use.  (Named registers, no array: an array read through selects would be placed in scratch memory.)
     typedef float vec4f __attribute__((ext_vector_type(4)));
     vec4f v0, v1, v2, v3, v4, v5, v6, v7;
     if (vec_ok && len == CHUNK) {
@@ -136,78 +138,103 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
     }
     const float pre = p.pre_logit;
-    unsigned int pending = 0u;                     // bit it*4+k: that element may reach the threshold
+    unsigned int pending_all = 0u;                 // bit it*4+k: that element may reach the threshold
     auto mark = [&](const vec4f& v, int it) {
         unsigned int m = 0u;
         m |= !(v.x <= pre) ? 1u : 0u; m |= !(v.y <= pre) ? 2u : 0u;
         m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
-        pending |= m << (it * 4);
+        pending_all |= m << (it * 4);
     };
     if (p.prefilter) {
         mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
     } else {
-        pending = 0xffffffffu;                     // threshold <= 0: every element is scored
+        pending_all = 0xffffffffu;                 // threshold <= 0: every element is scored
     }
     if (len < CHUNK) {
         unsigned int in_range = 0u;
 #pragma unroll
         for (int i = 0; i < ITERS * 4; ++i)
             in_range |= ((i >> 2) * ST * 4 + tid * 4 + (i & 3) < len) ? (1u << i) : 0u;
-        pending &= in_range;
+        pending_all &= in_range;
     }
+    const int all_total = (int)wave_sum_all((uint32_t)__popc(pending_all));
+    if (lane == 0) s_tot[wave] = all_total;
+    __syncthreads();
+    int wg_total = 0, before_me = 0;
+    bool one_pass = true;
+#pragma unroll
+    for (int w = 0; w < ST / 64; ++w) {
+        const int t = s_tot[w];
+        wg_total += t;
+        if (w < wave) before_me += t;
+        one_pass = one_pass && t <= QCAP;
+    }
+    if (wg_total == 0) return;                     // nothing in this chunk can pass
 
-    // queue the positions (offsets inside the chunk) of the pending elements, lane after lane
-    const int mine = __popc(pending);
-    const int incl = wave_inclusive_sum(mine);
-    const int total = __builtin_amdgcn_readlane(incl, 63);
-    if (total == 0) return;                        // nothing in this wave's 2048 logits can pass
-    unsigned short* queue = s_queue[wave];
-    {
+    unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
+    unsigned int* counter = key_count + ((long long)b * p.num_levels + l) * CSTRIDE;
+    unsigned long long* queue = s_queue[wave];
+    // Usual case: every wave's queue holds all its candidates; the workgroup reserves its slots with ONE
+    // atomic, requested before the scoring.  Otherwise each wave makes four passes of 8 element slots
+    // (at most 64 * 8 = QCAP entries each) with a reservation of its own per pass.
+    unsigned int wg_base = 0;                      // requested now, stored to LDS only after the scoring
+    if (one_pass && tid == 0) wg_base = atomicAdd(counter, (unsigned int)wg_total);
+    const int passes = one_pass ? 1 : 4;
+    for (int ps = 0; ps < passes; ++ps) {
+        unsigned int pending = one_pass ? pending_all : (pending_all & (0xffu << (8 * ps)));
+        const int mine = __popc(pending);
+        const int incl = wave_inclusive_sum(mine);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        unsigned int base = 0;
+        if (!one_pass && total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
         int pos = incl - mine;
         while (pending) {
             const int e = __ffs(pending) - 1;
             pending &= pending - 1u;
-            queue[pos++] = (unsigned short)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+            // xe = element e through a select tree
+            const bool b0 = e & 1, b1 = e & 2;
+            const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
+            const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
+            const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
+            const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
+            const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
+            const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
+            const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
+            const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
+            const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
+            const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
+            const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
+            const float xe = b4 ? h1 : h0;
+            const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+            queue[pos++] = ((unsigned long long)f2u(xe) << 32) | off;     // (logit, position in the chunk)
         }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
-    unsigned int* counter = key_count + ((long long)b * p.num_levels + l) * CSTRIDE;
-    unsigned long long* buf = s_buf[wave];
-    int staged = 0;                                // wave-uniform
-    auto flush = [&]() {
-        if (staged == 0) return;
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(counter, (unsigned int)staged);
-        base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
-        for (int i = lane; i < staged; i += 64) dst[base + i] = buf[i];
-        staged = 0;
-    };
-    for (int i0 = 0; i0 < total; i0 += 64) {
-        const bool active = i0 + lane < total;
-        float sc = 0.0f;
-        bool pass = false;
-        long long flat = 0;
-        if (active) {
-            flat = e0 + queue[i0 + lane];
-            sc = score_of(p, l, b, src[flat], flat);   // the logit was just streamed through the cache
-            pass = sc > p.thresh;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i0 = 0; i0 < total; i0 += 64) {   // every lane scores its own entry and overwrites it with the key
+            if (i0 + lane < total) {
+                const unsigned long long ent = queue[i0 + lane];
+                const long long flat = e0 + (long long)(uint32_t)ent;
+                const float sc = score_of(p, l, b, u2f((uint32_t)(ent >> 32)), flat);
+                queue[i0 + lane] = (sc > p.thresh) ? (((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat)) : 0ull;
+            }
         }
-        const uint64_t bal = __ballot(pass);
-        const int n = __popcll(bal);
-        if (staged + n > WCAP) flush();
-        if (pass) buf[staged + mbcnt(bal)] = ((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat);
-        staged += n;
+        if (one_pass) {
+            if (tid == 0) s_base = wg_base;
+            __syncthreads();
+            base = s_base + (unsigned int)before_me;
+        } else {
+            base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
+        }
+        for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
     }
-    flush();
 }
 
 // ---- block-wide helpers for the select kernel ----------------------------------------------------
 // Finds, from the top, the histogram bin in which the running count reaches `need`.
-// Returns (bin, keys in the bins above it, keys in it) through s_tmp[16..18]; all threads must call it.
+// Returns (bin, keys in the bins above it, keys in it) through s_tmp[16..18] and found = 1 in s_tmp[19];
+// if the histogram holds fewer than `need` keys, s_tmp[19] = 0 and s_tmp[17] = its total.
+// All threads must call it.
 __device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb, int need, int* s_tmp) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (nb + SEL_T - 1) / SEL_T;     // 4 when nb = 4096, else 1 (nb <= 1024)
@@ -221,6 +248,11 @@ __device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb,
     int higher = 0;                               // keys in waves above this one
     for (int i = wave + 1; i < SEL_T / 64; ++i) higher += s_tmp[i];
     const int above_me = higher + suf - local;    // keys in bins strictly above my bins
+    if (tid == 0) {                               // thread 0 owns the lowest bins: above_me + local = all keys
+        const int all = above_me + local;
+        s_tmp[19] = all >= need ? 1 : 0;
+        if (all < need) { s_tmp[16] = 0; s_tmp[17] = all; s_tmp[18] = 0; }
+    }
     if (above_me < need && need <= above_me + local) {
         int acc = above_me;
         for (int i = per - 1; i >= 0; --i) {
@@ -353,12 +385,13 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             __syncthreads();
             const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
             stream_keys(keys, total, [&](unsigned long long k) {
-                if (k >= lo && (k - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k - lo) >> shift)], 1u);
+                if (k != 0ull && k >= lo && (k - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k - lo) >> shift)], 1u);
             });
             __syncthreads();
             find_cut_bin(s_hist, nb, need, s_tmp);
-            const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18];
+            const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18], found = s_tmp[19];
             __syncthreads();
+            if (!found) break;                     // fewer valid keys than K: everything at or above lo is taken
             lo = lo + ((unsigned long long)bstar << shift);
             w = shift;
             const int n_ge = (K - need) + above + h;
@@ -388,15 +421,21 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
         for (int u = 0; u < CAP / SEL_T; ++u) {
             const int i = u * SEL_T + tid;
             k[u] = i < cnt ? s_keys[i] : 0ull;
-            if (i < cnt && k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
+            if (k[u] != 0ull && k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
         }
         __syncthreads();
         find_cut_bin(s_hist, nb, need, s_tmp);
-        const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18];
-        lo = lo + ((unsigned long long)bstar << shift);
-        w = shift;
-        const int n_ge = (K - need) + above + h;
-        need -= above;
+        const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18], found = s_tmp[19];
+        int n_ge;
+        if (found) {
+            lo = lo + ((unsigned long long)bstar << shift);
+            w = shift;
+            n_ge = (K - need) + above + h;
+            need -= above;
+        } else {                                     // fewer valid keys than K (zero keys inflated cnt): keep them all
+            n_ge = (K - need) + above;               // `above` = all valid keys of the interval
+            w = 0;
+        }
         // compact in place: every thread holds its keys in registers, so the buffer can be rewritten
 #pragma unroll
         for (int u = 0; u < CAP / SEL_T; ++u) lds_append(k[u] >= lo && k[u] != 0ull, k[u], s_keys, &s_tmp[20], CAP);
@@ -412,7 +451,14 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
 
     block_bitonic_sort_desc<SEL_T>(sorted, n_pad);
 
-    const int n_out = cnt < K ? cnt : K;
+    // zero keys (slots the filter reserved for logits that then failed the exact threshold) sort last
+    if (tid == 0) s_tmp[21] = 0;
+    __syncthreads();
+    for (int i = tid; i < cnt; i += SEL_T)
+        if (sorted[i] != 0ull && (i + 1 == n_pad || sorted[i + 1] == 0ull)) s_tmp[21] = i + 1;
+    __syncthreads();
+    const int valid = s_tmp[21];
+    const int n_out = valid < K ? valid : K;
     for (int r = tid; r < n_out; r += SEL_T)
         decode_store(p, l, b, sorted[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
     if (tid == 0) cand_count[b * num_levels + l] = n_out;

@@ -280,3 +280,20 @@ def test_match_retinanet_heavy_entry_overflow(device):
     for b, g in enumerate(gts):
         ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, True)
         assert np.array_equal(out[b].numpy(), ref), f"image {b}"
+
+
+def test_select_prefilter_margin_leaves_empty_slots(device):
+    """Logits inside the prefilter margin (just below logit(thresh)) are queued but fail the exact threshold:
+    their reserved slots hold zero keys, which the top-k must ignore -- also when fewer than K real keys
+    remain among thousands of empty slots."""
+    gen = torch.Generator().manual_seed(5)
+    # thresh 0.5 -> logit 0; the prefilter bound is -1e-3: values in (-1e-3, 0] are queued and then rejected
+    band = lambda shape: -torch.rand(shape, generator=gen) * 0.9e-3
+    mix = torch.empty((2, 30000, 3)).uniform_(-0.002, 0.002, generator=gen)          # ~45k pass, ~20k empty slots
+    _check_select_single_level(device, mix, 3, 0.5, 1000)
+    few = band((2, 1800, 3))                                                          # 5400 empty slots (fit in LDS) ...
+    few[0].view(-1)[torch.randperm(5400, generator=gen)[:300]] = 1.5                  # ... and 300 real keys < K
+    _check_select_single_level(device, few, 3, 0.5, 1000)
+    many = band((2, 7000, 3))                                                         # 21000 empty slots (beyond LDS)
+    many[1].view(-1)[torch.randperm(21000, generator=gen)[:700]] = 2.0
+    _check_select_single_level(device, many, 3, 0.5, 1000)
