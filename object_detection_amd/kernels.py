@@ -33,8 +33,11 @@ def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
 
 
 def _workspace(device: torch.device, tag: str, nbytes: int) -> Tensor:
-    """Grow-only per-(device, tag) scratch buffer; torch returns 256-byte aligned blocks."""
-    key = (device.index, tag)
+    """Grow-only scratch buffer per (device, stream, tag); torch returns 256-byte aligned blocks.
+
+    Keyed by the current stream as well: calls enqueued on different streams may run concurrently and
+    must not share scratch memory."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -81,13 +84,17 @@ def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tup
 
 
 def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, Tensor, int]:
-    counts = [int(g.shape[0]) for g in gt_list]
     offsets = [0]
-    for c in counts:
-        offsets.append(offsets[-1] + c)
+    plain = True                      # every tensor already fp32 [M, 4]: concatenate as they are
+    for g in gt_list:
+        offsets.append(offsets[-1] + g.shape[0])
+        plain = plain and g.dtype is torch.float32 and g.dim() == 2
     m_total = offsets[-1]
     if m_total > 0:
-        gt = torch.cat([_f32c(g.reshape(-1, 4)) for g in gt_list if g.shape[0] > 0]).contiguous()
+        if plain:
+            gt = torch.cat(gt_list)   # cat returns a fresh contiguous tensor; empty [0, 4] entries are fine
+        else:
+            gt = torch.cat([_f32c(g.reshape(-1, 4)) for g in gt_list if g.shape[0] > 0]).contiguous()
     else:
         gt = torch.zeros((1, 4), dtype=torch.float32, device=device)
     return gt, _device_ints(offsets, device), m_total
@@ -214,15 +221,22 @@ def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor]
     if plan is None:
         plan = _plans[key] = SelectPlan(sizes, B, C, dev)
 
+    f32 = torch.float32
+
     def prep(levels, inner):
         out, strides = [], []
         for t in levels:
-            if t.dtype != torch.float32:
+            if t.dtype is not f32:
                 t = t.float()
-            if t.dim() == 3 and not (t.stride(2) == 1 and t.stride(1) == inner):
-                t = t.contiguous()
+            if t.dim() == 3:
+                st = t.stride()
+                if st[2] != 1 or st[1] != inner:
+                    t = t.contiguous()
+                    st = t.stride()
+                strides.append(st[0])
+            else:
+                strides.append(0)
             out.append(t)
-            strides.append(int(t.stride(0)) if t.dim() == 3 else 0)
         return out, strides
 
     cls_t, cls_s = prep(cls_levels, C)

@@ -219,3 +219,42 @@ def test_full_size_cfg2_two_images_and_batch_properties(device):
         assert int(m.max()) < cfg.num_gt and int(m.min()) >= -2
         # the low-quality restore guarantees foreground anchors exist whenever GT boxes overlap anchors
         assert int((m >= 0).sum()) >= 1
+
+
+def test_concurrent_streams_do_not_share_scratch(device):
+    """Steps enqueued on different HIP streams may overlap on the GPU; every stream has its own scratch buffers,
+    so the results must equal those of the same calls made one after the other."""
+    base = synthetic.CFG1
+    cfgs = [dataclasses.replace(base, cfg_id=40 + i, num_gt=60) for i in range(3)]
+    model = _model(base, device)
+    anchors_l = _anchors(model, base, device)
+    anchors = torch.cat(anchors_l)
+    sizes = synthetic.level_sizes(base)
+    shapes = [base.image_size] * base.batch
+    work = []
+    for cfg in cfgs:
+        head = {k: v.to(device) for k, v in synthetic.make_head_outputs(cfg).items()}
+        split = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+        gts = [t["boxes"].to(device) for t in synthetic.make_targets(cfg)]
+        work.append((split, gts))
+
+    def run(split, gts):
+        out = postprocess_batched(split["cls_logits"], split["bbox_regression"], [anchors_l] * base.batch, shapes,
+                                  model.score_thresh, model.topk_candidates, model.nms_thresh, model.detections_per_img,
+                                  _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip, return_padded=True)
+        return out + (kernels.match_retinanet(anchors, gts, 0.6, 0.5, True),)
+
+    ref = [run(*w) for w in work]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device) for _ in work]
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream(device))
+    got = [None] * len(work)
+    for rep in range(6):                         # several rounds, so that launches of different streams interleave
+        for i, w in enumerate(work):
+            with torch.cuda.stream(streams[i]):
+                got[i] = run(*w)
+    torch.cuda.synchronize()
+    for i in range(len(work)):
+        for a, b in zip(got[i], ref[i]):
+            assert torch.equal(a, b), f"stream {i}"

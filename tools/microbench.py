@@ -71,7 +71,7 @@ def main():
         n = anchors.shape[-2]
         tiles = len(gts) * ((n + 255) // 256)
         off = a256(m_total * 4 * 32) + a256(len(gts) * n * 4) + a256(tiles * 4) + a256(tiles * 24 * 8) + a256(len(gts) * 4)
-        ws = kernels._workspaces[(anchors.device.index, "match")]
+        ws = kernels._workspaces[(anchors.device.index, torch.cuda.current_stream(anchors.device).cuda_stream, "match")]
         hc = ws[off + 256:off + 256 + len(gts) * 128].view(torch.int64)[::16]
         res["match_counters"] = {"heavy_tiles": int((hc >> 32).sum()), "heavy_entries": int((hc & 0xffffffff).sum()),
                                  "tiles": tiles}
@@ -95,7 +95,7 @@ def main():
     if os.environ.get("OD_STAMPS"):
         kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh, _C.NMS_AUTO_GPU, 500, want_keep_idx=False)
         torch.cuda.synchronize()
-        ws = kernels._workspaces[(dev.index, "nms")]
+        ws = kernels._workspaces[(dev.index, torch.cuda.current_stream(dev).cuda_stream, "nms")]
         off = cfg.batch * 7 * 8192 * 4
         st = ws[off:off + cfg.batch * 256].view(torch.int64).view(cfg.batch, 32).cpu()
         for b in (0, 5):
