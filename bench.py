@@ -111,8 +111,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=3, help="images in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the steps alternate between (consecutive steps may then overlap on the GPU)")
+    ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3),
+                    help="2: the inference half and the training half of a step run on HIP streams of their own; "
+                         "3: in addition the inference halves of consecutive steps alternate between two streams")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,24 +152,22 @@ def main():
     # inside the timed region.  A step therefore never stalls the GPU on a host round trip.
     counts_host = torch.empty((max(args.steps, args.warmup, 3), cfg.batch), dtype=torch.int32).pin_memory()
 
-    # Consecutive steps go to alternating HIP streams: the narrow kernels of one step (top-k: 96 workgroups, NMS: one
-    # workgroup per image) then run beside the chip-wide kernels of the next.  Scratch buffers are per stream.
-    streams = [torch.cuda.Stream(dev) for _ in range(max(1, args.streams))]
-    for st in streams:
+    # The two halves of a step are independent, so each gets a HIP stream of its own: the narrow kernels of the
+    # inference half (top-k: 96 workgroups, NMS: one workgroup per image) then run beside the chip-wide matching
+    # kernels instead of leaving most CUs idle.  Scratch buffers are per stream (kernels._workspace).
+    # With a third stream the inference halves of consecutive steps alternate between two streams, so that the
+    # NMS of one step also runs beside the score filter of the next.
+    two = args.streams >= 2
+    s_posts = [torch.cuda.Stream(dev) for _ in range(args.streams - 1)] if two else [torch.cuda.current_stream(dev)]
+    s_match = torch.cuda.Stream(dev) if two else torch.cuda.current_stream(dev)
+    for st in s_posts + [s_match]:
         st.wait_stream(torch.cuda.current_stream(dev))
 
-    def step(i=0, sync_host=False):
-        if len(streams) > 1 and not sync_host:
-            with torch.cuda.stream(streams[i % len(streams)]):
-                return step_body(i, False)
-        return step_body(i, sync_host)
-
-    def step_body(i, sync_host):
+    def run_post(i, sync_host):
         ob, os_, ol, oc = postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
                                               model.score_thresh, model.topk_candidates, model.nms_thresh,
                                               model.detections_per_img, _C.CODER_BOXCODER,
                                               model.box_coder.bbox_xform_clip, return_padded=True)
-        matched = model.match_anchors(targets, anchors_per_image)
         if world > 1:
             packed = sharding.pack_detections(ob, os_, ol)
             sharding.all_gather_detections(packed, oc)
@@ -176,7 +175,17 @@ def main():
             oc.tolist()
         else:
             counts_host[i].copy_(oc, non_blocking=True)
-        return matched, oc
+        return oc
+
+    def step(i=0, sync_host=False):
+        if two and not sync_host:
+            with torch.cuda.stream(s_posts[i % len(s_posts)]):
+                oc = run_post(i, False)
+            with torch.cuda.stream(s_match):
+                matched = model.match_anchors(targets, anchors_per_image)
+            return matched, oc
+        oc = run_post(i, sync_host)
+        return model.match_anchors(targets, anchors_per_image), oc
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -185,7 +194,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    for i in range(max(args.warmup, len(streams))):       # every stream allocates its scratch buffers here
+    for i in range(max(args.warmup, 2)):                  # every stream allocates its scratch buffers here
         step(i % counts_host.shape[0])
     sync()
 
@@ -292,7 +301,7 @@ def main():
                 "logits": "synthetic 'stress' distribution N(-3, 1.5) + 0.1% saturated: 2.3% of the logits pass "
                           "score_thresh, every level overflows topk_candidates",
                 "parallelism": f"image-sharded x{world}" + (", all-gather of detections (RCCL)" if world > 1 else ""),
-                "hip_streams": len(streams),
+                "hip_streams": args.streams,
             },
             "roofline": {
                 "kernel": dominant,
