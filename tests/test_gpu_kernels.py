@@ -297,3 +297,26 @@ def test_select_prefilter_margin_leaves_empty_slots(device):
     many = band((2, 7000, 3))                                                         # 21000 empty slots (beyond LDS)
     many[1].view(-1)[torch.randperm(21000, generator=gen)[:700]] = 2.0
     _check_select_single_level(device, many, 3, 0.5, 1000)
+
+
+def test_match_retinanet_dense_targets(device):
+    """2000 GT boxes per image (the dense-matching configuration, on the small pyramid): the GT list is streamed in
+    chunks instead of staying in registers, and almost every tile goes through the cooperative kernel."""
+    grids = (64, 32, 16, 8, 4)
+    ag, anchors = _anchors_cpu((512, 512), grids, synthetic.retinanet_anchor_sizes(5, 32))
+    gts = []
+    for b, m in enumerate((2000, 1300)):
+        gen = torch.Generator().manual_seed(900 + b)
+        gts.append(synthetic.make_gt_boxes(m, (512, 512), gen))
+    out = kernels.match_retinanet(anchors.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+    for b, g in enumerate(gts):
+        ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, True)
+        assert np.array_equal(out[b].numpy(), ref), f"image {b}"
+
+
+def test_select_many_classes(device):
+    """91 classes (flat index = anchor * 91 + class), low score threshold, K above and below the candidate count."""
+    gen = torch.Generator().manual_seed(21)
+    logits = torch.empty((2, 3000, 91)).normal_(-4.0, 1.5, generator=gen)
+    for thr, K in ((0.05, 1000), (0.3, 4096)):
+        _check_select_single_level(device, logits, 91, thr, K)
