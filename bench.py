@@ -111,7 +111,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=3, help="images in the CPU-baseline sample (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3),
+    ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3, 4),
                     help="2: the inference half and the training half of a step run on HIP streams of their own; "
                          "3: in addition the inference halves of consecutive steps alternate between two streams")
     args = ap.parse_args()
@@ -158,9 +158,10 @@ def main():
     # With a third stream the inference halves of consecutive steps alternate between two streams, so that the
     # NMS of one step also runs beside the score filter of the next.
     two = args.streams >= 2
-    s_posts = [torch.cuda.Stream(dev) for _ in range(args.streams - 1)] if two else [torch.cuda.current_stream(dev)]
-    s_match = torch.cuda.Stream(dev) if two else torch.cuda.current_stream(dev)
-    for st in s_posts + [s_match]:
+    n_post = {1: 1, 2: 1, 3: 2, 4: 2}[args.streams]
+    s_posts = [torch.cuda.Stream(dev) for _ in range(n_post)] if two else [torch.cuda.current_stream(dev)]
+    s_matches = [torch.cuda.Stream(dev) for _ in range(args.streams - n_post)] if two else [torch.cuda.current_stream(dev)]
+    for st in s_posts + s_matches:
         st.wait_stream(torch.cuda.current_stream(dev))
 
     def run_post(i, sync_host):
@@ -181,7 +182,7 @@ def main():
         if two and not sync_host and not single_stream:
             with torch.cuda.stream(s_posts[i % len(s_posts)]):
                 oc = run_post(i, False)
-            with torch.cuda.stream(s_match):
+            with torch.cuda.stream(s_matches[i % len(s_matches)]):
                 matched = model.match_anchors(targets, anchors_per_image)
             return matched, oc
         oc = run_post(i, sync_host)
