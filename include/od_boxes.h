@@ -159,6 +159,29 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
                    size_t workspace_bytes, void* stream);
 
 /*
+ * Classification loss of the RetinaNet head, fused with its target construction.  Replaces torchvision
+ * RetinaNetClassificationHead.compute_loss = per image sigmoid_focal_loss(logits[valid], target[valid], "sum")
+ * / max(1, #foreground), averaged over the batch (head built at reference retinanet_model.py:47-54, loss taken at
+ * train.py:62-63).  target[a, c] = 1 iff matched[a] >= 0 and gt_labels[matched[a]] == c; anchors with
+ * matched == -2 are ignored.
+ *   cls_logits : fp32 [batch, n, num_classes], images batch_stride elements apart
+ *   matched    : int64 [batch, n] as written by od_match_retinanet;  gt_labels: int64 [gt_offsets[batch]]
+ *   forward  -> loss fp32 [1] (mean over images), per_image_loss fp32 [batch], num_foreground int32 [batch]
+ *   backward -> grad_logits fp32 [batch, n, num_classes] (contiguous) = grad_loss[0] * d loss / d cls_logits,
+ *               from the forward's num_foreground
+ * Floating point: agrees with the fp32 torch evaluation to about 1e-6 relative (tests use 1e-5).
+ */
+size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, int32_t batch);
+int od_focal_loss_forward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+                          const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
+                          float alpha, float gamma, float* loss, float* per_image_loss, int32_t* num_foreground,
+                          void* workspace, size_t workspace_bytes, void* stream);
+int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+                           const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
+                           float alpha, float gamma, const int32_t* num_foreground, const float* grad_loss,
+                           float* grad_logits, void* stream);
+
+/*
  * Per-kernel timing aid.  No counterpart in the reference (it has no profiling hooks); used by
  * bench.py to measure a kernel's own duration on the stream it runs on.  od_profile_select makes the
  * library bracket every later launch of that kernel (or of all kernels) with hipEvents;
@@ -179,7 +202,9 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
 #define OD_KERNEL_NMS 9
 #define OD_KERNEL_MATCH_HEAVY 10     /* od_match_retinanet: cooperative kernel for GT-heavy tiles */
 #define OD_KERNEL_MATCH_FLAG 11
-#define OD_KERNEL_COUNT 12
+#define OD_KERNEL_FOCAL_FWD 12      /* od_focal_loss_forward (stream + finalize)                 */
+#define OD_KERNEL_FOCAL_BWD 13
+#define OD_KERNEL_COUNT 14
 int od_profile_select(int32_t kernel_id);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 

@@ -1,12 +1,13 @@
 """Matcher / box coders / loss helpers with the interfaces of
 ``torchvision.models.detection._utils`` (0.16.2), which the reference's models are built from
 (``object_detection/retinanet/retinanet_model.py:4-7``).  Index-producing work runs in HIP kernels;
-differentiable loss arithmetic (downstream of matching) stays in PyTorch autograd.
+the classification-head loss has a fused
+forward/backward kernel pair; the remaining differentiable arithmetic (box losses) stays in PyTorch autograd.
 """
 from __future__ import annotations
 
 import math
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 from torch import Tensor
@@ -168,3 +169,50 @@ def _box_loss(type: str, box_coder: BoxCoder, anchors_per_image: Tensor, matched
     pred = box_coder.decode_single(bbox_regression_per_image, anchors_per_image)
     eps = torch.finfo(bbox_regression_per_image.dtype).eps
     return generalized_box_iou_loss(pred, matched_gt_boxes_per_image, reduction="sum", eps=eps)
+
+
+class _RetinaNetFocalLoss(torch.autograd.Function):
+    """Classification-head loss of a whole batch in one streamed pass each way (kernels.focal_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
+                gamma: float) -> Tensor:
+        loss, _, num_fg = kernels.focal_loss_forward(cls_logits, matched, gt_labels, gt_offsets, alpha, gamma)
+        ctx.save_for_backward(cls_logits, matched, gt_labels, gt_offsets, num_fg)
+        ctx.alpha, ctx.gamma = alpha, gamma
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        cls_logits, matched, gt_labels, gt_offsets, num_fg = ctx.saved_tensors
+        g = grad_out.reshape(1).to(torch.float32).contiguous()
+        grad = kernels.focal_loss_backward(cls_logits, matched, gt_labels, gt_offsets, ctx.alpha, ctx.gamma, num_fg, g)
+        return grad, None, None, None, None, None
+
+
+def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor], labels: List[Tensor],
+                                  alpha: float = 0.25, gamma: float = 2.0) -> Optional[Tensor]:
+    """Fused path of RetinaNetClassificationHead.compute_loss; None if the inputs do not qualify (not on the GPU,
+    not fp32, or logits whose inner dimensions are not contiguous) and the caller should use the torch ops."""
+    if not (cls_logits.is_cuda and cls_logits.dtype is torch.float32 and cls_logits.dim() == 3):
+        return None
+    if cls_logits.stride(2) != 1 or cls_logits.stride(1) != cls_logits.shape[2]:
+        return None
+    B, n = cls_logits.shape[0], cls_logits.shape[1]
+    first = matched_idxs[0]
+    step = n * first.element_size()
+    if first.dtype is torch.int64 and first.is_contiguous() and all(
+            m.data_ptr() == first.data_ptr() + i * step and m.shape == first.shape for i, m in enumerate(matched_idxs)):
+        matched = first.as_strided((B, n), (n, 1))          # the rows of one [B, N] tensor (what match_anchors returns)
+    else:
+        matched = torch.stack([m.to(torch.int64) for m in matched_idxs])
+    offsets = [0]
+    for lab in labels:
+        offsets.append(offsets[-1] + lab.shape[0])
+    if offsets[-1] > 0:
+        gt_labels = torch.cat([lab.to(torch.int64) for lab in labels])
+    else:
+        gt_labels = torch.zeros((1,), dtype=torch.int64, device=cls_logits.device)
+    gt_offsets = kernels._device_ints(offsets, cls_logits.device)
+    return _RetinaNetFocalLoss.apply(cls_logits, matched, gt_labels, gt_offsets, float(alpha), float(gamma))
+

@@ -297,3 +297,36 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
                             _ptr(ws), ws.numel(), _stream(dev))
     _C.check(rc, "od_batched_nms")
     return keep_idx, out_boxes, out_scores, out_labels, out_count
+
+
+# ------------------------------------------------------------------------------------------------
+def focal_loss_forward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
+                       gamma: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """RetinaNet classification loss for a batch.  cls_logits [B,N,C] fp32 (inner dims contiguous), matched int64
+    [B,N], gt_labels int64 [sum M], gt_offsets int32 [B+1].  Returns (loss [1], per_image [B], num_fg int32 [B])."""
+    _require_gpu(cls_logits, "cls_logits")
+    dev = cls_logits.device
+    B, n, C = cls_logits.shape
+    lib = _C.lib()
+    ws = _workspace(dev, "focal", lib.od_focal_loss_workspace_bytes(n, C, B))
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    per_image = torch.empty((B,), dtype=torch.float32, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    rc = lib.od_focal_loss_forward(_ptr(cls_logits), cls_logits.stride(0), n, C, _ptr(matched), _ptr(gt_labels),
+                                   _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(loss), _ptr(per_image),
+                                   _ptr(num_fg), _ptr(ws), ws.numel(), _stream(dev))
+    _C.check(rc, "od_focal_loss_forward")
+    return loss, per_image, num_fg
+
+
+def focal_loss_backward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
+                        gamma: float, num_fg: Tensor, grad_loss: Tensor) -> Tensor:
+    dev = cls_logits.device
+    B, n, C = cls_logits.shape
+    grad = torch.empty((B, n, C), dtype=torch.float32, device=dev)
+    rc = _C.lib().od_focal_loss_backward(_ptr(cls_logits), cls_logits.stride(0), n, C, _ptr(matched), _ptr(gt_labels),
+                                         _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(num_fg),
+                                         _ptr(grad_loss), _ptr(grad), _stream(dev))
+    _C.check(rc, "od_focal_loss_backward")
+    return grad
+

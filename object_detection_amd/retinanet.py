@@ -69,6 +69,10 @@ class RetinaNetClassificationHead(nn.Module):
         self.BETWEEN_THRESHOLDS = det_utils.Matcher.BETWEEN_THRESHOLDS
 
     def compute_loss(self, targets, head_outputs, matched_idxs) -> Tensor:
+        fused = det_utils.retinanet_classification_loss(head_outputs["cls_logits"], list(matched_idxs),
+                                                        [t["labels"] for t in targets])
+        if fused is not None:
+            return fused
         losses = []
         for t, logits, m in zip(targets, head_outputs["cls_logits"], matched_idxs):
             fg = m >= 0

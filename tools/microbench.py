@@ -92,6 +92,29 @@ def main():
         for thr in (0.05, 0.9):
             res[f"nms_thr{thr}_keep500"] = timed(lambda: kernels.batched_nms_padded(cb, cs, cl, cc, K, True, thr,
                                                                                    _C.NMS_AUTO_GPU, 500, want_keep_idx=False))
+    if args.what in ("all", "loss"):
+        from object_detection_amd import det_utils
+        head = synthetic.make_head_outputs(cfg, logits=args.logits)
+        cls = head["cls_logits"].to(dev)
+        targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)
+        gts = [t["boxes"].to(dev) for t in targets]
+        labels = [t["labels"].to(dev) for t in targets]
+        matched = kernels.match_retinanet(anchors, gts, 0.6, 0.5, True)
+        offs = [0]
+        for lab in labels:
+            offs.append(offs[-1] + lab.shape[0])
+        gl, go = torch.cat(labels), kernels._device_ints(offs, dev)
+        one = torch.ones((1,), device=dev)
+
+        def fwd_bwd():
+            _, _, nfg = kernels.focal_loss_forward(cls, matched, gl, go, 0.25, 2.0)
+            kernels.focal_loss_backward(cls, matched, gl, go, 0.25, 2.0, nfg, one)
+
+        res["loss"] = timed(fwd_bwd)
+        res["loss_forward_only_loop"] = timed(lambda: kernels.focal_loss_forward(cls, matched, gl, go, 0.25, 2.0))
+        E = cls.numel()
+        res["loss_GBps"] = {"focal_fwd": (4 * E + 8 * matched.numel()) / (res["loss"]["focal_fwd"] * 1e-6) / 1e9,
+                            "focal_bwd": (8 * E + 8 * matched.numel()) / (res["loss"]["focal_bwd"] * 1e-6) / 1e9}
     if os.environ.get("OD_STAMPS"):
         kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh, _C.NMS_AUTO_GPU, 500, want_keep_idx=False)
         torch.cuda.synchronize()
