@@ -182,6 +182,34 @@ int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_
                            float* grad_logits, void* stream);
 
 /*
+ * Regression loss of the RetinaNet head.  Replaces torchvision RetinaNetRegressionHead.compute_loss =
+ * per image _box_loss(type, box_coder, anchors[fg], gt_boxes[matched[fg]], bbox_regression[fg]) / max(1, #fg) over the
+ * foreground anchors fg = matched >= 0, averaged over the batch.  The reference selects type "giou"
+ * (reference retinanet_model.py:53: generalized_box_iou_loss of the decoded boxes, eps = fp32 machine epsilon);
+ * "l1" (torchvision's default) and "smooth_l1" compare the regression with BoxCoder.encode_single(gt, anchor).
+ *   bbox_regression: fp32 [batch, n, 4], images batch_stride elements apart (16-byte aligned rows)
+ *   anchors        : fp32 [n, 4]; images anchor_batch_stride elements apart, 0 = one table shared by all images
+ *   matched        : int64 [batch, n];  gt_boxes: fp32 [gt_offsets[batch], 4];  weights: 4 host floats (BoxCoder)
+ *   forward  -> loss fp32 [1], per_image_loss fp32 [batch], num_foreground int32 [batch]
+ *   backward -> grad_regression fp32 [batch, n, 4] (contiguous; zero rows for anchors that are not foreground)
+ * Floating point: fp32 in the operation order of the torch evaluation; tests use 1e-5 relative.
+ */
+#define OD_BOX_LOSS_L1 0
+#define OD_BOX_LOSS_SMOOTH_L1 1
+#define OD_BOX_LOSS_GIOU 2
+size_t od_box_loss_workspace_bytes(int64_t n, int32_t batch);
+int od_box_loss_forward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+                        int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                        const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta, const float* weights,
+                        float bbox_xform_clip, float eps, float* loss, float* per_image_loss, int32_t* num_foreground,
+                        void* workspace, size_t workspace_bytes, void* stream);
+int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+                         int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                         const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta, const float* weights,
+                         float bbox_xform_clip, float eps, const int32_t* num_foreground, const float* grad_loss,
+                         float* grad_regression, void* stream);
+
+/*
  * Per-kernel timing aid.  No counterpart in the reference (it has no profiling hooks); used by
  * bench.py to measure a kernel's own duration on the stream it runs on.  od_profile_select makes the
  * library bracket every later launch of that kernel (or of all kernels) with hipEvents;
@@ -202,9 +230,11 @@ int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_
 #define OD_KERNEL_NMS 9
 #define OD_KERNEL_MATCH_HEAVY 10     /* od_match_retinanet: cooperative kernel for GT-heavy tiles */
 #define OD_KERNEL_MATCH_FLAG 11
-#define OD_KERNEL_FOCAL_FWD 12      /* od_focal_loss_forward (stream + finalize)                 */
+#define OD_KERNEL_FOCAL_FWD 12      /* od_focal_loss_forward: the streaming kernel               */
 #define OD_KERNEL_FOCAL_BWD 13
-#define OD_KERNEL_COUNT 14
+#define OD_KERNEL_BOX_LOSS_FWD 14   /* od_box_loss_forward: the streaming kernel                 */
+#define OD_KERNEL_BOX_LOSS_BWD 15
+#define OD_KERNEL_COUNT 16
 int od_profile_select(int32_t kernel_id);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 

@@ -356,6 +356,238 @@ int fill_args(LossArgs* a, const float* cls_logits, int64_t batch_stride, int64_
     return OD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Regression loss of the RetinaNet head (torchvision RetinaNetRegressionHead.compute_loss -> _utils._box_loss):
+// per image, over the foreground anchors (matched >= 0):
+//   "giou"      : sum generalized_box_iou_loss(BoxCoder.decode_single(regression, anchor), gt, eps)
+//   "l1"        : sum |regression - BoxCoder.encode_single(gt, anchor)|
+//   "smooth_l1" : the same difference through smooth_l1(beta)
+// divided by max(1, #foreground), then averaged over the batch.  The reference selects "giou"
+// (reference object_detection/retinanet/retinanet_model.py:53).  The kernels stream the matched indices and touch
+// regression / anchor / target box only where an anchor is foreground; the arithmetic there uses the full-precision
+// exp / log / division, since it is a tiny share of the work.
+constexpr int RT = 256;                 // threads per workgroup
+constexpr int RPT = 8;                  // anchors per thread
+constexpr int RCHUNK = RT * RPT;
+
+struct BoxLossArgs {
+    const float* reg;                   // [batch, n, 4]
+    long long reg_stride;               // elements between images
+    const float* anchors;               // [n, 4]; images anchor_stride elements apart (0: shared by all images)
+    long long anchor_stride;
+    const long long* matched;           // [batch, n]
+    const float* gt_boxes;              // [sum M, 4]
+    const int* gt_offsets;              // [batch + 1]
+    long long n;
+    int loss_type;
+    float beta, wx, wy, ww, wh, clip, eps;
+    int blocks_per_image;
+};
+
+struct BoxTerms {
+    float loss;
+    float4 grad;                        // d loss / d regression
+};
+
+// derivative of max(a, b) (sel = a > b) or min(a, b) (sel = a < b) with respect to a, torch's tie rule (one half)
+__device__ __forceinline__ float pick(bool sel, float a, float b) { return sel ? 1.0f : (a == b ? 0.5f : 0.0f); }
+
+__device__ __forceinline__ BoxTerms giou_terms(const BoxLossArgs& p, float4 r, float4 a, float4 g) {
+    // BoxCoder.decode_single
+    const float w = a.z - a.x, h = a.w - a.y;
+    const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
+    const float dx = r.x / p.wx, dy = r.y / p.wy;
+    const float dw0 = r.z / p.ww, dh0 = r.w / p.wh;
+    const float dw = fminf(dw0, p.clip), dh = fminf(dh0, p.clip);
+    const float pcx = dx * w + cx, pcy = dy * h + cy;
+    const float pw = expf(dw) * w, ph = expf(dh) * h;
+    const float hw = 0.5f * pw, hh = 0.5f * ph;
+    const float x1 = pcx - hw, y1 = pcy - hh, x2 = pcx + hw, y2 = pcy + hh;
+    // generalized_box_iou_loss
+    const float ix1 = fmaxf(x1, g.x), iy1 = fmaxf(y1, g.y), ix2 = fminf(x2, g.z), iy2 = fminf(y2, g.w);
+    const bool hit = (iy2 > iy1) && (ix2 > ix1);
+    const float iw = ix2 - ix1, ih = iy2 - iy1;
+    const float inter = hit ? iw * ih : 0.0f;
+    const float bw = x2 - x1, bh = y2 - y1;
+    const float uni = bw * bh + (g.z - g.x) * (g.w - g.y) - inter;
+    const float ue = uni + p.eps;
+    const float iou = inter / ue;
+    const float ex1 = fminf(x1, g.x), ey1 = fminf(y1, g.y), ex2 = fmaxf(x2, g.z), ey2 = fmaxf(y2, g.w);
+    const float ew = ex2 - ex1, eh = ey2 - ey1;
+    const float area_c = ew * eh;
+    const float ce = area_c + p.eps;
+    BoxTerms t;
+    t.loss = 1.0f - (iou - (area_c - uni) / ce);
+    // backward: loss = 1 - I/(U+eps) + (C-U)/(C+eps),  U = A_pred + A_gt - I
+    const float dI = -(1.0f / ue + inter / (ue * ue)) + 1.0f / ce;
+    const float dU = inter / (ue * ue) - 1.0f / ce;                 // reaches the box through A_pred
+    const float dC = ue / (ce * ce);
+    float gx1 = dU * -bh + dC * -eh * pick(x1 < g.x, x1, g.x);
+    float gy1 = dU * -bw + dC * -ew * pick(y1 < g.y, y1, g.y);
+    float gx2 = dU * bh + dC * eh * pick(x2 > g.z, x2, g.z);
+    float gy2 = dU * bw + dC * ew * pick(y2 > g.w, y2, g.w);
+    if (hit) {
+        gx1 += dI * -ih * pick(x1 > g.x, x1, g.x);
+        gy1 += dI * -iw * pick(y1 > g.y, y1, g.y);
+        gx2 += dI * ih * pick(x2 < g.z, x2, g.z);
+        gy2 += dI * iw * pick(y2 < g.w, y2, g.w);
+    }
+    // through decode_single; clamp passes the gradient where the value is not above the bound
+    t.grad.x = (gx1 + gx2) * w / p.wx;
+    t.grad.y = (gy1 + gy2) * h / p.wy;
+    t.grad.z = (dw0 <= p.clip) ? 0.5f * (gx2 - gx1) * pw / p.ww : 0.0f;
+    t.grad.w = (dh0 <= p.clip) ? 0.5f * (gy2 - gy1) * ph / p.wh : 0.0f;
+    return t;
+}
+
+__device__ __forceinline__ void l1_term(float d, float beta, float& loss, float& grad) {
+    const float ad = fabsf(d);
+    if (ad < beta) {                                                // smooth_l1 only (beta == 0 for plain l1)
+        loss = 0.5f * d * d / beta;
+        grad = d / beta;
+    } else {
+        loss = ad - 0.5f * beta;
+        grad = (d > 0.0f) ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+    }
+}
+
+__device__ __forceinline__ BoxTerms l1_terms(const BoxLossArgs& p, float4 r, float4 a, float4 g) {
+    // BoxCoder.encode_single(gt, anchor)
+    const float aw = a.z - a.x, ah = a.w - a.y;
+    const float acx = a.x + 0.5f * aw, acy = a.y + 0.5f * ah;
+    const float gw = g.z - g.x, gh = g.w - g.y;
+    const float gcx = g.x + 0.5f * gw, gcy = g.y + 0.5f * gh;
+    const float tx = p.wx * (gcx - acx) / aw, ty = p.wy * (gcy - acy) / ah;
+    const float tw = p.ww * logf(gw / aw), th = p.wh * logf(gh / ah);
+    BoxTerms t;
+    float l0, l1, l2, l3;
+    l1_term(r.x - tx, p.beta, l0, t.grad.x);
+    l1_term(r.y - ty, p.beta, l1, t.grad.y);
+    l1_term(r.z - tw, p.beta, l2, t.grad.z);
+    l1_term(r.w - th, p.beta, l3, t.grad.w);
+    t.loss = ((l0 + l1) + l2) + l3;
+    return t;
+}
+
+// Terms of anchor `a` of image b if it is foreground; returns false (and touches nothing) otherwise.
+__device__ __forceinline__ bool box_terms_of(const BoxLossArgs& p, int b, long long a, long long m, BoxTerms& t) {
+    const int m0 = p.gt_offsets[b];
+    if (m < 0 || m >= (long long)(p.gt_offsets[b + 1] - m0)) return false;
+    const float4 r = *reinterpret_cast<const float4*>(p.reg + (long long)b * p.reg_stride + a * 4);
+    const float4 an = *reinterpret_cast<const float4*>(p.anchors + (long long)b * p.anchor_stride + a * 4);
+    const float4 g = *reinterpret_cast<const float4*>(p.gt_boxes + (long long)(m0 + m) * 4);
+    t = (p.loss_type == OD_BOX_LOSS_GIOU) ? giou_terms(p, r, an, g) : l1_terms(p, r, an, g);
+    return true;
+}
+
+__global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, double* __restrict__ part_loss,
+                                                              int* __restrict__ part_fg) {
+    __shared__ float s_sum[RT / 64];
+    __shared__ int s_fg[RT / 64];
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long long a0 = (long long)blockIdx.x * RCHUNK;
+    const long long* mrow = p.matched + (long long)b * p.n;
+    long long m[RPT];
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        const long long a = a0 + it * RT + tid;
+        m[it] = (a < p.n) ? __builtin_nontemporal_load(mrow + a) : -1;
+    }
+    float acc = 0.0f;
+    int fg = 0;
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        BoxTerms t;
+        if (box_terms_of(p, b, a0 + it * RT + tid, m[it], t)) {
+            acc += t.loss;
+            ++fg;
+        }
+    }
+    float wsum = acc;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+    const int wfg = (int)wave_sum_all((uint32_t)fg);
+    if ((tid & 63) == 0) { s_sum[tid >> 6] = wsum; s_fg[tid >> 6] = wfg; }
+    __syncthreads();
+    if (tid == 0) {
+        double t = 0.0;
+        int f = 0;
+#pragma unroll
+        for (int w = 0; w < RT / 64; ++w) { t += (double)s_sum[w]; f += s_fg[w]; }
+        part_loss[(long long)b * p.blocks_per_image + blockIdx.x] = t;
+        part_fg[(long long)b * p.blocks_per_image + blockIdx.x] = f;
+    }
+}
+
+__global__ __launch_bounds__(RT) void box_loss_backward_kernel(BoxLossArgs p, const int* __restrict__ num_fg,
+                                                               const float* __restrict__ grad_out, int batch,
+                                                               float* __restrict__ grad_reg) {
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x;
+    const long long a0 = (long long)blockIdx.x * RCHUNK;
+    const long long* mrow = p.matched + (long long)b * p.n;
+    float* dst = grad_reg + (long long)b * p.n * 4;                  // the gradient is written contiguously
+    long long m[RPT];
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        const long long a = a0 + it * RT + tid;
+        m[it] = (a < p.n) ? __builtin_nontemporal_load(mrow + a) : -1;
+    }
+    const int nf = num_fg[b];
+    const float scale = *grad_out / ((float)(nf > 1 ? nf : 1) * (float)batch);
+#pragma unroll
+    for (int it = 0; it < RPT; ++it) {
+        const long long a = a0 + it * RT + tid;
+        float4 gr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        BoxTerms t;
+        if (box_terms_of(p, b, a, m[it], t))
+            gr = make_float4(scale * t.grad.x, scale * t.grad.y, scale * t.grad.z, scale * t.grad.w);
+        if (a < p.n) *reinterpret_cast<float4*>(dst + a * 4) = gr;
+    }
+}
+
+bool box_loss_layout(int64_t n, int32_t batch, int* blocks, size_t* part_bytes, size_t* total) {
+    if (n < 0 || batch < 0) return false;
+    const long long blk = (n + RCHUNK - 1) / RCHUNK;
+    if (blk > 0x7fffffff) return false;
+    *blocks = (int)blk;
+    *part_bytes = (((size_t)batch * (size_t)blk * sizeof(double)) + 255) & ~(size_t)255;
+    *total = *part_bytes + ((((size_t)batch * (size_t)blk * sizeof(int)) + 255) & ~(size_t)255);
+    return true;
+}
+
+int fill_box_args(BoxLossArgs* a, const float* reg, int64_t reg_stride, const float* anchors, int64_t anchor_stride,
+                  int64_t n, const int64_t* matched, const float* gt_boxes, const int32_t* gt_offsets, int32_t loss_type,
+                  float beta, const float* weights, float clip, float eps, int blocks) {
+    if (!reg || !anchors || !matched || !gt_offsets || !weights) return OD_ERR_ARG;
+    if (reg_stride < n * 4 || (anchor_stride != 0 && anchor_stride < n * 4)) return OD_ERR_ARG;
+    // rows are read as 16-byte vectors
+    if (((uintptr_t)reg & 15) || (reg_stride & 3) || ((uintptr_t)anchors & 15) || (anchor_stride & 3) ||
+        ((uintptr_t)gt_boxes & 15) || ((uintptr_t)matched & 7))
+        return OD_ERR_ARG;
+    if (loss_type != OD_BOX_LOSS_L1 && loss_type != OD_BOX_LOSS_SMOOTH_L1 && loss_type != OD_BOX_LOSS_GIOU)
+        return OD_ERR_ARG;
+    if (loss_type == OD_BOX_LOSS_SMOOTH_L1 && !(beta >= 0.0f)) return OD_ERR_ARG;
+    for (int k = 0; k < 4; ++k)
+        if (!(weights[k] != 0.0f)) return OD_ERR_ARG;
+    a->reg = reg;
+    a->reg_stride = reg_stride;
+    a->anchors = anchors;
+    a->anchor_stride = anchor_stride;
+    a->matched = (const long long*)matched;
+    a->gt_boxes = gt_boxes;
+    a->gt_offsets = gt_offsets;
+    a->n = n;
+    a->loss_type = loss_type;
+    a->beta = (loss_type == OD_BOX_LOSS_SMOOTH_L1) ? beta : 0.0f;
+    a->wx = weights[0]; a->wy = weights[1]; a->ww = weights[2]; a->wh = weights[3];
+    a->clip = clip;
+    a->eps = eps;
+    a->blocks_per_image = blocks;
+    return OD_OK;
+}
+
 }  // namespace
 
 extern "C" size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, int32_t batch) {
@@ -423,5 +655,65 @@ extern "C" int od_focal_loss_backward(const float* cls_logits, int64_t batch_str
                   hipLaunchKernelGGL(focal_backward_kernel<false>, dim3((unsigned)blocks, (unsigned)batch), dim3(LT), 0, s,
                                      a, num_foreground, grad_loss, (int)batch, grad_logits));
     }
+    return OD_OK;
+}
+
+extern "C" size_t od_box_loss_workspace_bytes(int64_t n, int32_t batch) {
+    int blocks;
+    size_t part, total;
+    if (!box_loss_layout(n, batch, &blocks, &part, &total)) return 0;
+    return total > 0 ? total : 256;
+}
+
+extern "C" int od_box_loss_forward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+                                   int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                                   const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta,
+                                   const float* weights, float bbox_xform_clip, float eps, float* loss,
+                                   float* per_image_loss, int32_t* num_foreground, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    int blocks;
+    size_t part, total;
+    if (!box_loss_layout(n, batch, &blocks, &part, &total)) return OD_ERR_ARG;
+    if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
+    if (!loss || !per_image_loss || !num_foreground || !workspace) return OD_ERR_ARG;
+    if (workspace_bytes < total || ((uintptr_t)workspace & 255)) return OD_ERR_WORKSPACE;
+    BoxLossArgs a;
+    const int rc = fill_box_args(&a, bbox_regression, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
+                                 gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
+    if (rc != OD_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    double* part_loss = (double*)workspace;
+    int* part_fg = (int*)((char*)workspace + part);
+    if (blocks > 0) {
+        OD_LAUNCH(OD_KERNEL_BOX_LOSS_FWD, s,
+                  hipLaunchKernelGGL(box_loss_forward_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(RT), 0, s, a,
+                                     part_loss, part_fg));
+    }
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
+                       blocks, (int)batch, loss, per_image_loss, num_foreground);
+    OD_LAUNCH_CHECK();
+    return OD_OK;
+}
+
+extern "C" int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+                                    int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                                    const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta,
+                                    const float* weights, float bbox_xform_clip, float eps,
+                                    const int32_t* num_foreground, const float* grad_loss, float* grad_regression,
+                                    void* stream) {
+    int blocks;
+    size_t part, total;
+    if (!box_loss_layout(n, batch, &blocks, &part, &total)) return OD_ERR_ARG;
+    if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
+    if (!num_foreground || !grad_loss || !grad_regression || ((uintptr_t)grad_regression & 15)) return OD_ERR_ARG;
+    BoxLossArgs a;
+    const int rc = fill_box_args(&a, bbox_regression, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
+                                 gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
+    if (rc != OD_OK) return rc;
+    if (blocks == 0) return OD_OK;
+    hipStream_t s = (hipStream_t)stream;
+    OD_LAUNCH(OD_KERNEL_BOX_LOSS_BWD, s,
+              hipLaunchKernelGGL(box_loss_backward_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(RT), 0, s, a,
+                                 num_foreground, grad_loss, (int)batch, grad_regression));
     return OD_OK;
 }

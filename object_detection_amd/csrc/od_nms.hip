@@ -30,7 +30,6 @@ using namespace od;
 
 constexpr int NT = 1024;              // threads per workgroup
 constexpr int S = 256;                // strip length
-constexpr int PARTS = NT / S;         // thread groups splitting the kept list in phase A
 constexpr int SB = S / 64;            // 64-candidate blocks per strip
 constexpr int MAXN = OD_MAX_NMS_BOXES;
 constexpr int MERGE_MAX = 6144;       // merge-path ordering needs a second key buffer of this many keys

@@ -190,6 +190,17 @@ class _RetinaNetFocalLoss(torch.autograd.Function):
         return grad, None, None, None, None, None
 
 
+def _matched_rows(matched_idxs: List[Tensor], n: int) -> Tensor:
+    """[B, N] int64 view of the per-image matched indices (no copy when they are the rows of one tensor, which is what
+    match_anchors returns)."""
+    first = matched_idxs[0]
+    step = n * first.element_size()
+    if first.dtype is torch.int64 and first.is_contiguous() and all(
+            m.data_ptr() == first.data_ptr() + i * step and m.shape == first.shape for i, m in enumerate(matched_idxs)):
+        return first.as_strided((len(matched_idxs), n), (n, 1))
+    return torch.stack([m.to(torch.int64) for m in matched_idxs])
+
+
 def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor], labels: List[Tensor],
                                   alpha: float = 0.25, gamma: float = 2.0) -> Optional[Tensor]:
     """Fused path of RetinaNetClassificationHead.compute_loss; None if the inputs do not qualify (not on the GPU,
@@ -199,13 +210,7 @@ def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor]
     if cls_logits.stride(2) != 1 or cls_logits.stride(1) != cls_logits.shape[2]:
         return None
     B, n = cls_logits.shape[0], cls_logits.shape[1]
-    first = matched_idxs[0]
-    step = n * first.element_size()
-    if first.dtype is torch.int64 and first.is_contiguous() and all(
-            m.data_ptr() == first.data_ptr() + i * step and m.shape == first.shape for i, m in enumerate(matched_idxs)):
-        matched = first.as_strided((B, n), (n, 1))          # the rows of one [B, N] tensor (what match_anchors returns)
-    else:
-        matched = torch.stack([m.to(torch.int64) for m in matched_idxs])
+    matched = _matched_rows(matched_idxs, n)
     offsets = [0]
     for lab in labels:
         offsets.append(offsets[-1] + lab.shape[0])
@@ -216,3 +221,60 @@ def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor]
     gt_offsets = kernels._device_ints(offsets, cls_logits.device)
     return _RetinaNetFocalLoss.apply(cls_logits, matched, gt_labels, gt_offsets, float(alpha), float(gamma))
 
+
+class _RetinaNetBoxLoss(torch.autograd.Function):
+    """Regression-head loss of a whole batch: one pass over the matched indices each way (kernels.box_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, bbox_regression: Tensor, anchors: Tensor, matched: Tensor, gt_boxes: Tensor, gt_offsets: Tensor,
+                loss_type: int, beta: float, weights, clip: float, eps: float) -> Tensor:
+        conf = (loss_type, beta, tuple(weights), clip, eps)
+        loss, _, num_fg = kernels.box_loss_forward(bbox_regression, anchors, matched, gt_boxes, gt_offsets, *conf)
+        ctx.save_for_backward(bbox_regression, anchors, matched, gt_boxes, gt_offsets, num_fg)
+        ctx.conf = conf
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        bbox_regression, anchors, matched, gt_boxes, gt_offsets, num_fg = ctx.saved_tensors
+        g = grad_out.reshape(1).to(torch.float32).contiguous()
+        grad = kernels.box_loss_backward(bbox_regression, anchors, matched, gt_boxes, gt_offsets, *ctx.conf, num_fg, g)
+        return (grad,) + (None,) * 9
+
+
+_BOX_LOSS_TYPES = {"l1": _C.BOX_LOSS_L1, "smooth_l1": _C.BOX_LOSS_SMOOTH_L1, "giou": _C.BOX_LOSS_GIOU}
+
+
+def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: Tensor, anchors: List[Tensor],
+                              matched_idxs: List[Tensor], gt_boxes: List[Tensor], cnf=None) -> Optional[Tensor]:
+    """Fused path of RetinaNetRegressionHead.compute_loss; None if the inputs do not qualify (not on the GPU, not
+    fp32, rows not contiguous, anchors or targets that need a gradient) and the caller should use the torch ops."""
+    torch._assert(type in _BOX_LOSS_TYPES, f"Unsupported loss: {type}")
+    if not (bbox_regression.is_cuda and bbox_regression.dtype is torch.float32 and bbox_regression.dim() == 3):
+        return None
+    B, n = bbox_regression.shape[0], bbox_regression.shape[1]
+    if (bbox_regression.shape[2] != 4 or bbox_regression.stride(2) != 1 or bbox_regression.stride(1) != 4
+            or bbox_regression.stride(0) % 4 or bbox_regression.data_ptr() % 16):
+        return None
+    if any(a.requires_grad or a.dtype is not torch.float32 or a.shape != (n, 4) for a in anchors):
+        return None
+    if any(g.requires_grad for g in gt_boxes):
+        return None
+    first = anchors[0]
+    if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
+        anchor_table = first.contiguous()                    # AnchorGenerator hands every image the same tensor
+    else:
+        anchor_table = torch.stack([a.contiguous() for a in anchors])
+    matched = _matched_rows(matched_idxs, n)
+    offsets = [0]
+    for g in gt_boxes:
+        offsets.append(offsets[-1] + g.shape[0])
+    if offsets[-1] > 0:
+        boxes = torch.cat([g.to(torch.float32).reshape(-1, 4) for g in gt_boxes])
+    else:
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=bbox_regression.device)
+    gt_offsets = kernels._device_ints(offsets, bbox_regression.device)
+    beta = float(cnf["beta"]) if cnf is not None and "beta" in cnf else 1.0
+    eps = float(torch.finfo(bbox_regression.dtype).eps)
+    return _RetinaNetBoxLoss.apply(bbox_regression, anchor_table, matched, boxes, gt_offsets, _BOX_LOSS_TYPES[type], beta,
+                                   tuple(float(w) for w in box_coder.weights), float(box_coder.bbox_xform_clip), eps)

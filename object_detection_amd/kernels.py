@@ -330,3 +330,43 @@ def focal_loss_backward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, 
     _C.check(rc, "od_focal_loss_backward")
     return grad
 
+
+def _box_loss_call_args(bbox_regression: Tensor, anchors: Tensor, matched: Tensor, gt_boxes: Tensor, gt_offsets: Tensor,
+                        loss_type: int, beta: float, weights: Sequence[float], clip: float, eps: float):
+    B, n, _ = bbox_regression.shape
+    anchor_stride = 0 if anchors.dim() == 2 else anchors.stride(0)
+    w = (ctypes.c_float * 4)(*[float(x) for x in weights])
+    return (_ptr(bbox_regression), bbox_regression.stride(0), _ptr(anchors), anchor_stride, n, _ptr(matched),
+            _ptr(gt_boxes), _ptr(gt_offsets), B, int(loss_type), float(beta), w, float(clip), float(eps))
+
+
+def box_loss_forward(bbox_regression: Tensor, anchors: Tensor, matched: Tensor, gt_boxes: Tensor, gt_offsets: Tensor,
+                     loss_type: int, beta: float, weights: Sequence[float], clip: float,
+                     eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """RetinaNet regression loss for a batch.  bbox_regression [B,N,4] fp32 (inner dims contiguous), anchors [N,4]
+    (shared) or [B,N,4], matched int64 [B,N], gt_boxes fp32 [sum M,4], gt_offsets int32 [B+1].
+    Returns (loss [1], per_image [B], num_fg int32 [B])."""
+    _require_gpu(bbox_regression, "bbox_regression")
+    dev = bbox_regression.device
+    B, n, _ = bbox_regression.shape
+    lib = _C.lib()
+    ws = _workspace(dev, "box_loss", lib.od_box_loss_workspace_bytes(n, B))
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    per_image = torch.empty((B,), dtype=torch.float32, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    args = _box_loss_call_args(bbox_regression, anchors, matched, gt_boxes, gt_offsets, loss_type, beta, weights, clip, eps)
+    rc = lib.od_box_loss_forward(*args, _ptr(loss), _ptr(per_image), _ptr(num_fg), _ptr(ws), ws.numel(), _stream(dev))
+    _C.check(rc, "od_box_loss_forward")
+    return loss, per_image, num_fg
+
+
+def box_loss_backward(bbox_regression: Tensor, anchors: Tensor, matched: Tensor, gt_boxes: Tensor, gt_offsets: Tensor,
+                      loss_type: int, beta: float, weights: Sequence[float], clip: float, eps: float, num_fg: Tensor,
+                      grad_loss: Tensor) -> Tensor:
+    dev = bbox_regression.device
+    B, n, _ = bbox_regression.shape
+    grad = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    args = _box_loss_call_args(bbox_regression, anchors, matched, gt_boxes, gt_offsets, loss_type, beta, weights, clip, eps)
+    rc = _C.lib().od_box_loss_backward(*args, _ptr(num_fg), _ptr(grad_loss), _ptr(grad), _stream(dev))
+    _C.check(rc, "od_box_loss_backward")
+    return grad

@@ -99,6 +99,12 @@ class RetinaNetRegressionHead(nn.Module):
         self._loss_type = "l1"
 
     def compute_loss(self, targets, head_outputs, anchors, matched_idxs) -> Tensor:
+        if len(targets) > 0:
+            fused = det_utils.retinanet_regression_loss(self._loss_type, self.box_coder, head_outputs["bbox_regression"],
+                                                        list(anchors), list(matched_idxs),
+                                                        [t["boxes"] for t in targets])
+            if fused is not None:
+                return fused
         losses = []
         for t, reg, a, m in zip(targets, head_outputs["bbox_regression"], anchors, matched_idxs):
             fg = torch.where(m >= 0)[0]

@@ -201,6 +201,20 @@ class BoxCoder:
         self.weights = weights
         self.bbox_xform_clip = bbox_xform_clip
 
+    def encode_single(self, reference_boxes: Tensor, proposals: Tensor) -> Tensor:
+        """torchvision _utils.encode_boxes: regression targets of ``reference_boxes`` relative to ``proposals``."""
+        wx, wy, ww, wh = self.weights
+        ex_widths = proposals[:, 2] - proposals[:, 0]
+        ex_heights = proposals[:, 3] - proposals[:, 1]
+        ex_ctr_x = proposals[:, 0] + 0.5 * ex_widths
+        ex_ctr_y = proposals[:, 1] + 0.5 * ex_heights
+        gt_widths = reference_boxes[:, 2] - reference_boxes[:, 0]
+        gt_heights = reference_boxes[:, 3] - reference_boxes[:, 1]
+        gt_ctr_x = reference_boxes[:, 0] + 0.5 * gt_widths
+        gt_ctr_y = reference_boxes[:, 1] + 0.5 * gt_heights
+        return torch.stack((wx * (gt_ctr_x - ex_ctr_x) / ex_widths, wy * (gt_ctr_y - ex_ctr_y) / ex_heights,
+                            ww * torch.log(gt_widths / ex_widths), wh * torch.log(gt_heights / ex_heights)), dim=1)
+
     def decode_single(self, rel_codes: Tensor, boxes: Tensor, math: str = "torch") -> Tensor:
         boxes = boxes.to(rel_codes.dtype)
         widths = boxes[:, 2] - boxes[:, 0]
@@ -415,7 +429,34 @@ def retinanet_match_chunked(gt: Tensor, anchors: Tensor, fg_iou_thresh: float, b
     return matches
 
 
-def retinanet_head_loss(targets, head_outputs, anchors, matched_idxs, loss_type: str = "giou"):
+def retinanet_head_loss_regression(targets, bbox_regression, anchors, matched_idxs, loss_type: str = "giou",
+                                   beta: float = 1.0, coder: "BoxCoder" = None, eps: float = None):
+    """RetinaNetRegressionHead.compute_loss: _box_loss over the foreground anchors / max(1, #fg), batch mean."""
+    coder = BoxCoder() if coder is None else coder
+    reg_losses = []
+    for t, reg, a, m in zip(targets, bbox_regression, anchors, matched_idxs):
+        fg = torch.where(m >= 0)[0]
+        num_fg = fg.numel()
+        gt_boxes = t["boxes"][m[fg]]
+        reg_fg = reg[fg, :]
+        a_fg = a[fg, :]
+        if loss_type == "giou":
+            pred = coder.decode_single(reg_fg, a_fg)
+            e = torch.finfo(reg_fg.dtype).eps if eps is None else eps
+            loss = generalized_box_iou_loss(pred, gt_boxes, reduction="sum", eps=e)
+        elif loss_type == "l1":
+            loss = torch.nn.functional.l1_loss(reg_fg, coder.encode_single(gt_boxes, a_fg), reduction="sum")
+        elif loss_type == "smooth_l1":
+            loss = torch.nn.functional.smooth_l1_loss(reg_fg, coder.encode_single(gt_boxes, a_fg), reduction="sum",
+                                                      beta=beta)
+        else:
+            raise NotImplementedError(loss_type)
+        reg_losses.append(loss / max(1, num_fg))
+    return sum(reg_losses) / max(1, len(targets))
+
+
+def retinanet_head_loss(targets, head_outputs, anchors, matched_idxs, loss_type: str = "giou", beta: float = 1.0,
+                        coder: "BoxCoder" = None):
     """RetinaNetHead.compute_loss = classification (sigmoid focal, ignore -2) + regression (_box_loss)."""
     cls_losses = []
     for t, cls_logits, m in zip(targets, head_outputs["cls_logits"], matched_idxs):
@@ -426,24 +467,10 @@ def retinanet_head_loss(targets, head_outputs, anchors, matched_idxs, loss_type:
         valid = m != BETWEEN_THRESHOLDS
         cls_losses.append(sigmoid_focal_loss(cls_logits[valid], gt_classes_target[valid], reduction="sum")
                           / max(1, num_fg))
-    coder = BoxCoder()
-    reg_losses = []
-    for t, reg, a, m in zip(targets, head_outputs["bbox_regression"], anchors, matched_idxs):
-        fg = torch.where(m >= 0)[0]
-        num_fg = fg.numel()
-        gt_boxes = t["boxes"][m[fg]]
-        reg_fg = reg[fg, :]
-        a_fg = a[fg, :]
-        if loss_type == "giou":
-            pred = coder.decode_single(reg_fg, a_fg)
-            eps = torch.finfo(reg_fg.dtype).eps
-            loss = generalized_box_iou_loss(pred, gt_boxes, reduction="sum", eps=eps)
-        else:
-            raise NotImplementedError(loss_type)
-        reg_losses.append(loss / max(1, num_fg))
     return {
         "classification": sum(cls_losses) / len(targets),
-        "bbox_regression": sum(reg_losses) / max(1, len(targets)),
+        "bbox_regression": retinanet_head_loss_regression(targets, head_outputs["bbox_regression"], anchors, matched_idxs,
+                                                          loss_type, beta, coder),
     }
 
 

@@ -360,3 +360,58 @@ def test_focal_loss_kernels_class_counts_and_ragged_sizes(device, num_classes, n
         tol = 1e-5 * gr.abs().max() + 1e-4 * gr.abs()
         assert bool(((grad - gr).abs() <= tol).all()), (alpha, gamma, float((grad - gr).abs().max()))
         assert torch.equal(grad[matched == -2], torch.zeros_like(grad[matched == -2]))
+
+
+def _random_boxes(gen, count, extent=900.0):
+    xy = torch.rand((count, 2), generator=gen) * extent
+    wh = 8.0 + torch.rand((count, 2), generator=gen) * 192.0
+    return torch.cat([xy, xy + wh], dim=1)
+
+
+@pytest.mark.parametrize("loss_type", ["giou", "l1", "smooth_l1"])
+@pytest.mark.parametrize("n,shared_anchors", [(5000, True), (2048, False), (4099, True)])
+def test_box_loss_kernels(device, loss_type, n, shared_anchors):
+    """Fused regression loss (forward and backward) against the torch restatement of
+    RetinaNetRegressionHead.compute_loss evaluated in fp32 like the reference path (the centre differences of the
+    encoder cancel, so an fp64 evaluation differs from any fp32 one by more than the tolerance): loss 1e-5 relative,
+    gradient 1e-5 of its largest entry plus 1e-4 relative per element, exact zeros for anchors that are not foreground.  Covers a partial last chunk,
+    one anchor table for all images and one per image, an image without foreground, size deltas above the clamp
+    (no gradient there) and non-unit coder weights."""
+    g = torch.Generator().manual_seed(4000 + n + len(loss_type))
+    B, M = 3, 11
+    weights = (1.0, 1.0, 1.0, 1.0) if loss_type == "giou" else (10.0, 10.0, 5.0, 5.0)
+    anchors = _random_boxes(g, n) if shared_anchors else torch.stack([_random_boxes(g, n) for _ in range(B)])
+    gt = [_random_boxes(g, M) for _ in range(B)]
+    matched = torch.randint(-2, M, (B, n), generator=g)
+    matched[2] = torch.where(matched[2] >= 0, torch.full_like(matched[2], -1), matched[2])
+    # anchors matched to a target overlap it in a typical way: target = anchor moved and scaled a little
+    for b in range(B - 1):
+        a = anchors if shared_anchors else anchors[b]
+        pick = torch.nonzero(matched[b] == 0).flatten()[:1]
+        if pick.numel():
+            gt[b][0] = a[pick[0]] + torch.tensor([3.0, -2.0, 9.0, 4.0])
+    reg = torch.randn((B, n, 4), generator=g) * 0.5
+    reg[0, ::97, 2] = 5.0                                        # above log(1000/16): clamped, zero gradient
+    reg[1, 5::131, 3] = 4.5
+    coder = tv.BoxCoder(weights)
+    x = reg.clone().requires_grad_(True)
+    targets = [{"boxes": b} for b in gt]
+    a_list = [(anchors if shared_anchors else anchors[b]) for b in range(B)]
+    ref = tv.retinanet_head_loss_regression(targets, x, a_list, list(matched), loss_type, 0.3, coder,
+                                            eps=float(torch.finfo(torch.float32).eps))
+    ref.backward()
+    code = {"l1": _C.BOX_LOSS_L1, "smooth_l1": _C.BOX_LOSS_SMOOTH_L1, "giou": _C.BOX_LOSS_GIOU}[loss_type]
+    conf = (code, 0.3, weights, coder.bbox_xform_clip, float(torch.finfo(torch.float32).eps))
+    rd, ad, md = reg.to(device), anchors.to(device), matched.to(device)
+    gd, od = torch.cat(gt).to(device), kernels._device_ints([0, M, 2 * M, 3 * M], device)
+    loss, per_image, nfg = kernels.box_loss_forward(rd, ad, md, gd, od, *conf)
+    assert nfg.cpu().tolist() == [int((matched[b] >= 0).sum()) for b in range(B)]
+    assert per_image[2].item() == 0.0
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    grad = kernels.box_loss_backward(rd, ad, md, gd, od, *conf, nfg, torch.full((1,), 2.0, device=device)).cpu()
+    gr = 2.0 * x.grad
+    tol = 1e-5 * gr.abs().max() + 1e-4 * gr.abs()
+    assert bool(((grad - gr).abs() <= tol).all()), float((grad - gr).abs().max())
+    assert torch.equal(grad[matched < 0], torch.zeros_like(grad[matched < 0]))
+    if loss_type == "giou":
+        assert float(grad[0, ::97, 2].abs().max()) == 0.0

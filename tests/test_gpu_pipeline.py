@@ -301,6 +301,41 @@ def test_fused_classification_loss_forward_and_backward(device):
     assert abs(loss2.item() - float(ref2)) <= 1e-5 * abs(float(ref2)), (loss2.item(), float(ref2))
 
 
+def test_fused_regression_loss_through_the_head(device):
+    """RetinaNetRegressionHead.compute_loss on the GPU goes through the fused kernels ("giou", the type the reference
+    selects) and agrees with the torch restatement on the CPU: loss 1e-5 relative, gradient 1e-5 of its largest entry
+    plus 1e-4 relative per element."""
+    cfg = dataclasses.replace(synthetic.CFG1, num_gt=40, cfg_id=78)
+    model = _model(cfg, device)
+    assert model.head.regression_head._loss_type == "giou"
+    anchors_l = _anchors(model, cfg, device)
+    anchors_dev = torch.cat(anchors_l)
+    anchors = anchors_dev.cpu()
+    head = synthetic.make_head_outputs(cfg)
+    targets = synthetic.make_targets(cfg, empty_image=1)
+    matched = tv.retinanet_match([t["boxes"] for t in targets], [anchors] * cfg.batch, cfg.fg_iou_thresh, cfg.bg_iou_thresh)
+    reg_ref = head["bbox_regression"].clone().requires_grad_(True)
+    ref = tv.retinanet_head_loss_regression(targets, reg_ref, [anchors] * cfg.batch, matched)
+    (ref * 0.5).backward()
+    reg = head["bbox_regression"].to(device).requires_grad_(True)
+    t_dev = [{k: v.to(device) for k, v in t.items()} for t in targets]
+    m_dev = list(torch.stack(matched).to(device).unbind(0))
+    loss = model.head.regression_head.compute_loss(t_dev, {"bbox_regression": reg}, [anchors_dev] * cfg.batch, m_dev)
+    assert loss.grad_fn is not None and type(loss.grad_fn).__name__.startswith("_RetinaNetBoxLoss")
+    (loss * 0.5).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()), (loss.item(), ref.item())
+    g, gr = reg.grad.cpu(), reg_ref.grad
+    tol = 1e-5 * gr.abs().max() + 1e-4 * gr.abs()
+    assert bool(((g - gr).abs() <= tol).all()), float((g - gr).abs().max())
+    assert int((torch.stack(matched) >= 0).sum()) > 0
+    # the whole training loss dictionary of the model
+    losses = model.compute_loss(t_dev, {"cls_logits": head["cls_logits"].to(device), "bbox_regression": reg.detach()},
+                                [anchors_dev] * cfg.batch)
+    both = tv.retinanet_head_loss(targets, head, [anchors] * cfg.batch, matched)
+    for k in ("classification", "bbox_regression"):
+        assert abs(losses[k].item() - both[k].item()) <= 1e-5 * abs(both[k].item()), k
+
+
 def _targets_of(logits, matched, labels):
     t = torch.zeros_like(logits)
     fg = matched >= 0

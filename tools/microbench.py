@@ -110,6 +110,16 @@ def main():
             _, _, nfg = kernels.focal_loss_forward(cls, matched, gl, go, 0.25, 2.0)
             kernels.focal_loss_backward(cls, matched, gl, go, 0.25, 2.0, nfg, one)
 
+        reg = head["bbox_regression"].to(dev)
+        gb = torch.cat(gts)
+        bconf = (_C.BOX_LOSS_GIOU, 1.0, (1.0, 1.0, 1.0, 1.0), 4.135166556742356, 1.1920928955078125e-07)
+
+        def box_fwd_bwd():
+            _, _, nfg = kernels.box_loss_forward(reg, anchors, matched, gb, go, *bconf)
+            kernels.box_loss_backward(reg, anchors, matched, gb, go, *bconf, nfg, one)
+
+        res["box_loss"] = timed(box_fwd_bwd)
+        res["foreground_per_image"] = float((matched >= 0).sum().item()) / cfg.batch
         res["loss"] = timed(fwd_bwd)
         res["loss_forward_only_loop"] = timed(lambda: kernels.focal_loss_forward(cls, matched, gl, go, 0.25, 2.0))
         E = cls.numel()
