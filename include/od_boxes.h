@@ -138,6 +138,25 @@ int od_select_candidates(const float* const* cls_logits, const int64_t* cls_batc
                          void* stream);
 
 /*
+ * The same, reading the head's convolution outputs in their own channel-major layout, which removes the
+ * permute + reshape copy of torchvision RetinaNetClassificationHead.forward / RetinaNetRegressionHead.forward
+ * (`view(N,-1,K,H,W).permute(0,3,4,1,2).reshape(N,-1,K)`; heads built at reference retinanet_model.py:47-54):
+ *   cls_logits[l]      : [batch, A_l * num_classes, plane_size[l]]  (plane = H*W of the level, A_l = anchors per cell)
+ *   bbox_ctrness[l]    : [batch, A_l, plane_size[l]] or NULL;   bbox_regression[l]: [batch, A_l * 4, plane_size[l]]
+ *   level_size[l] = plane_size[l] * A_l;  anchors and all outputs as above -- flat indices, order and results are
+ *   identical to od_select_candidates on the permuted tensors.
+ */
+int od_select_candidates_planar(const float* const* cls_logits, const int64_t* cls_batch_stride,
+                                const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
+                                const float* const* bbox_regression, const int64_t* reg_batch_stride,
+                                const float* const* anchors, const int64_t* anchor_batch_stride,
+                                const int64_t* level_size, const int64_t* plane_size, int32_t num_levels,
+                                int32_t batch, int32_t num_classes, const int32_t* image_hw, float score_thresh,
+                                int32_t topk, int32_t coder, float bbox_xform_clip, float* cand_boxes,
+                                float* cand_scores, int32_t* cand_labels, int64_t* cand_index, int32_t* cand_count,
+                                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Class-batched NMS for a batch of images.  Replaces torchvision.ops.boxes.batched_nms
  * (_batched_nms_coordinate_trick / _batched_nms_vanilla) + the native torchvision::nms op +
  * `keep[:max_keep]` + the gather of boxes/scores/labels (tail of postprocess_detections).

@@ -43,6 +43,8 @@ SIGNATURES = {
     "od_select_candidates_workspace_bytes": (c_size_t, [_P, c_int32, c_int32, c_int32]),
     "od_select_candidates": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P, c_float,
                                        c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "od_select_candidates_planar": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P,
+                                              c_float, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),

@@ -50,6 +50,10 @@ struct FilterParams {
     float thresh;
     float pre_logit;                        // logits <= pre_logit can never pass the threshold
     int prefilter;                          // 0: threshold <= 0, every logit is scored
+    // Channel-major levels (the convolution's own [batch, A*C, H*W] layout): plane = H*W, chans = A*C; the element
+    // at memory position ch*plane + hw has flat index hw*chans + ch.  plane = 0: anchor-major [batch, N_l, C].
+    unsigned int plane[OD_MAX_LEVELS];
+    unsigned int chans[OD_MAX_LEVELS];
 };
 
 struct SelectParams {
@@ -65,13 +69,29 @@ struct SelectParams {
     long long anchor_stride[OD_MAX_LEVELS];
     long long key_off[OD_MAX_LEVELS];
     long long keys_per_image;
+    unsigned int plane[OD_MAX_LEVELS];      // channel-major regression [batch, A*4, plane]; 0: [batch, N_l, 4]
+    unsigned int apl[OD_MAX_LEVELS];        // A: anchors per location
 };
 
-__device__ __forceinline__ float score_of(const FilterParams& p, int l, int b, float x, long long flat) {
+// Flat index (anchor * C + class, anchors in (y, x, a) order) of the logit at memory position `pos` of its level.
+__device__ __forceinline__ uint32_t flat_of(const FilterParams& p, int l, uint32_t pos) {
+    const uint32_t plane = p.plane[l];
+    if (plane == 0) return pos;
+    const uint32_t ch = pos / plane;
+    return (pos - ch * plane) * p.chans[l] + ch;
+}
+
+__device__ __forceinline__ float score_of(const FilterParams& p, int l, int b, float x, uint32_t flat) {
     float s = spec_sigmoidf(x);
     if (p.has_ctr) {
-        long long a = flat / p.num_classes;
-        float c = p.ctr[l][(long long)b * p.ctr_stride[l] + a];
+        const uint32_t a = flat / (uint32_t)p.num_classes;
+        long long at = a;                                        // position of the anchor's centre-ness value
+        if (p.plane[l]) {
+            const uint32_t apl = p.chans[l] / (uint32_t)p.num_classes;
+            const uint32_t hw = a / apl;
+            at = (long long)(a - hw * apl) * p.plane[l] + hw;
+        }
+        float c = p.ctr[l][(long long)b * p.ctr_stride[l] + at];
         s = sqrtf(s * spec_sigmoidf(c));
     }
     return s;
@@ -214,7 +234,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         for (int i0 = 0; i0 < total; i0 += 64) {   // every lane scores its own entry and overwrites it with the key
             if (i0 + lane < total) {
                 const unsigned long long ent = queue[i0 + lane];
-                const long long flat = e0 + (long long)(uint32_t)ent;
+                const uint32_t flat = flat_of(p, l, (uint32_t)e0 + (uint32_t)ent);
                 const float sc = score_of(p, l, b, u2f((uint32_t)(ent >> 32)), flat);
                 queue[i0 + lane] = (sc > p.thresh) ? (((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat)) : 0ull;
             }
@@ -309,7 +329,14 @@ __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b
     const float score = u2f((uint32_t)(key >> 32));
     const uint32_t a = flat / (uint32_t)p.num_classes;
     const int label = (int)(flat - a * (uint32_t)p.num_classes);
-    const float4 r = *reinterpret_cast<const float4*>(p.reg[l] + ((long long)b * p.reg_stride[l] + a) * 4);
+    float4 r;
+    if (p.plane[l] == 0) {
+        r = *reinterpret_cast<const float4*>(p.reg[l] + ((long long)b * p.reg_stride[l] + a) * 4);
+    } else {                                                     // channel (a_i*4 + k) of location hw
+        const uint32_t hw = a / p.apl[l];
+        const float* rp = p.reg[l] + (long long)b * p.reg_stride[l] * 4 + (long long)(a - hw * p.apl[l]) * 4 * p.plane[l] + hw;
+        r = make_float4(rp[0], rp[p.plane[l]], rp[2ll * p.plane[l]], rp[3ll * p.plane[l]]);
+    }
     const float4 an = *reinterpret_cast<const float4*>(p.anchors[l] + ((long long)b * p.anchor_stride[l] + a) * 4);
     float x1, y1, x2, y2;
     if (p.coder == OD_CODER_BOXCODER) {
@@ -531,15 +558,17 @@ extern "C" size_t od_select_candidates_workspace_bytes(const int64_t* level_size
     return lay.keys_bytes + lay.counts_bytes;
 }
 
-extern "C" int od_select_candidates(const float* const* cls_logits, const int64_t* cls_batch_stride,
-                                    const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
-                                    const float* const* bbox_regression, const int64_t* reg_batch_stride,
-                                    const float* const* anchors, const int64_t* anchor_batch_stride,
-                                    const int64_t* level_size, int32_t num_levels, int32_t batch,
-                                    int32_t num_classes, const int32_t* image_hw, float score_thresh,
-                                    int32_t topk, int32_t coder, float bbox_xform_clip, float* cand_boxes,
-                                    float* cand_scores, int32_t* cand_labels, int64_t* cand_index,
-                                    int32_t* cand_count, void* workspace, size_t workspace_bytes, void* stream) {
+namespace {
+
+int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_batch_stride,
+                           const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
+                           const float* const* bbox_regression, const int64_t* reg_batch_stride,
+                           const float* const* anchors, const int64_t* anchor_batch_stride,
+                           const int64_t* level_size, const int64_t* plane_size, int32_t num_levels, int32_t batch,
+                           int32_t num_classes, const int32_t* image_hw, float score_thresh,
+                           int32_t topk, int32_t coder, float bbox_xform_clip, float* cand_boxes,
+                           float* cand_scores, int32_t* cand_labels, int64_t* cand_index,
+                           int32_t* cand_count, void* workspace, size_t workspace_bytes, void* stream) {
     if (!cls_logits || !cls_batch_stride || !bbox_regression || !reg_batch_stride || !anchors ||
         !anchor_batch_stride || !level_size || !image_hw || !cand_boxes || !cand_scores || !cand_labels ||
         !cand_count || !workspace)
@@ -579,6 +608,17 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
         sp.reg_stride[l] = on ? reg_batch_stride[l] / 4 : 0;     // in boxes
         sp.anchors[l] = on ? anchors[l] : nullptr;
         sp.anchor_stride[l] = on ? anchor_batch_stride[l] / 4 : 0;
+        fp.plane[l] = fp.chans[l] = sp.plane[l] = sp.apl[l] = 0;
+        if (on && plane_size && level_size[l] > 0) {
+            const long long plane = plane_size[l];
+            if (plane < 1 || level_size[l] % plane != 0) return OD_ERR_ARG;
+            const long long apl = level_size[l] / plane;
+            fp.plane[l] = sp.plane[l] = (unsigned int)plane;     // level_size * num_classes < 2^32 was checked above
+            fp.chans[l] = (unsigned int)(apl * num_classes);
+            sp.apl[l] = (unsigned int)apl;
+            if (cls_batch_stride[l] < level_size[l] * (long long)num_classes || reg_batch_stride[l] < level_size[l] * 4)
+                return OD_ERR_ARG;
+        }
         if (on && level_size[l] > 0) {
             if (!cls_logits[l] || !bbox_regression[l] || !anchors[l]) return OD_ERR_ARG;
             if (((uintptr_t)bbox_regression[l] & 15) || ((uintptr_t)anchors[l] & 15)) return OD_ERR_ARG;
@@ -629,6 +669,40 @@ extern "C" int od_select_candidates(const float* const* cls_logits, const int64_
                                  (int)num_levels, (const unsigned long long*)keys, (const unsigned int*)key_count,
                                  image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count));
     return OD_OK;
+}
+
+}  // namespace
+
+extern "C" int od_select_candidates(const float* const* cls_logits, const int64_t* cls_batch_stride,
+                                    const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
+                                    const float* const* bbox_regression, const int64_t* reg_batch_stride,
+                                    const float* const* anchors, const int64_t* anchor_batch_stride,
+                                    const int64_t* level_size, int32_t num_levels, int32_t batch,
+                                    int32_t num_classes, const int32_t* image_hw, float score_thresh,
+                                    int32_t topk, int32_t coder, float bbox_xform_clip, float* cand_boxes,
+                                    float* cand_scores, int32_t* cand_labels, int64_t* cand_index,
+                                    int32_t* cand_count, void* workspace, size_t workspace_bytes, void* stream) {
+    return select_candidates_impl(cls_logits, cls_batch_stride, bbox_ctrness, ctr_batch_stride, bbox_regression,
+                                  reg_batch_stride, anchors, anchor_batch_stride, level_size, nullptr, num_levels, batch,
+                                  num_classes, image_hw, score_thresh, topk, coder, bbox_xform_clip, cand_boxes,
+                                  cand_scores, cand_labels, cand_index, cand_count, workspace, workspace_bytes, stream);
+}
+
+extern "C" int od_select_candidates_planar(const float* const* cls_logits, const int64_t* cls_batch_stride,
+                                           const float* const* bbox_ctrness, const int64_t* ctr_batch_stride,
+                                           const float* const* bbox_regression, const int64_t* reg_batch_stride,
+                                           const float* const* anchors, const int64_t* anchor_batch_stride,
+                                           const int64_t* level_size, const int64_t* plane_size, int32_t num_levels,
+                                           int32_t batch, int32_t num_classes, const int32_t* image_hw,
+                                           float score_thresh, int32_t topk, int32_t coder, float bbox_xform_clip,
+                                           float* cand_boxes, float* cand_scores, int32_t* cand_labels,
+                                           int64_t* cand_index, int32_t* cand_count, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    if (!plane_size) return OD_ERR_ARG;
+    return select_candidates_impl(cls_logits, cls_batch_stride, bbox_ctrness, ctr_batch_stride, bbox_regression,
+                                  reg_batch_stride, anchors, anchor_batch_stride, level_size, plane_size, num_levels,
+                                  batch, num_classes, image_hw, score_thresh, topk, coder, bbox_xform_clip, cand_boxes,
+                                  cand_scores, cand_labels, cand_index, cand_count, workspace, workspace_bytes, stream);
 }
 
 extern "C" int od_decode_boxes(const float* rel_codes, const float* boxes, int64_t n, int32_t coder,

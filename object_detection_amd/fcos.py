@@ -39,8 +39,12 @@ class FCOSClassificationHead(nn.Module):
         nn.init.normal_(self.cls_logits.weight, std=0.01)
         nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_probability) / prior_probability))
 
+    def forward_maps(self, x: List[Tensor]) -> List[Tensor]:
+        """Per-level convolution outputs [B, A*C, H, W], before the permute + reshape of ``forward``."""
+        return [self.cls_logits(self.conv(f)) for f in x]
+
     def forward(self, x: List[Tensor]) -> Tensor:
-        return torch.cat([_to_anchor_major(self.cls_logits(self.conv(f)), self.num_classes) for f in x], dim=1)
+        return torch.cat([_to_anchor_major(m, self.num_classes) for m in self.forward_maps(x)], dim=1)
 
 
 class FCOSRegressionHead(nn.Module):
@@ -53,13 +57,19 @@ class FCOSRegressionHead(nn.Module):
             nn.init.normal_(layer.weight, std=0.01)
             nn.init.zeros_(layer.bias)
 
-    def forward(self, x: List[Tensor]) -> Tuple[Tensor, Tensor]:
+    def forward_maps(self, x: List[Tensor]) -> Tuple[List[Tensor], List[Tensor]]:
+        """Per-level (regression [B, A*4, H, W], centre-ness [B, A, H, W]) before the permute + reshape."""
         regs, ctrs = [], []
         for f in x:
             t = self.conv(f)
-            regs.append(_to_anchor_major(nn.functional.relu(self.bbox_reg(t)), 4))
-            ctrs.append(_to_anchor_major(self.bbox_ctrness(t), 1))
-        return torch.cat(regs, dim=1), torch.cat(ctrs, dim=1)
+            regs.append(nn.functional.relu(self.bbox_reg(t)))
+            ctrs.append(self.bbox_ctrness(t))
+        return regs, ctrs
+
+    def forward(self, x: List[Tensor]) -> Tuple[Tensor, Tensor]:
+        regs, ctrs = self.forward_maps(x)
+        return (torch.cat([_to_anchor_major(r, 4) for r in regs], dim=1),
+                torch.cat([_to_anchor_major(c, 1) for c in ctrs], dim=1))
 
 
 class FCOSHead(nn.Module):
@@ -111,6 +121,11 @@ class FCOSHead(nn.Module):
         cls_logits = self.classification_head(x)
         bbox_regression, bbox_ctrness = self.regression_head(x)
         return {"cls_logits": cls_logits, "bbox_regression": bbox_regression, "bbox_ctrness": bbox_ctrness}
+
+    def forward_maps(self, x: List[Tensor]) -> Dict[str, List[Tensor]]:
+        """Head outputs per level in the convolutions' own channel-major layout (inference path)."""
+        regs, ctrs = self.regression_head.forward_maps(x)
+        return {"cls_logits": self.classification_head.forward_maps(x), "bbox_regression": regs, "bbox_ctrness": ctrs}
 
 
 class FCOS(nn.Module):
@@ -190,6 +205,19 @@ class FCOS(nn.Module):
         if isinstance(features, torch.Tensor):
             features = OrderedDict([("0", features)])
         features = list(features.values())
+        if (not self.training and features[0].is_cuda and hasattr(self.head, "forward_maps")
+                and type(self).postprocess_detections is FCOS.postprocess_detections):
+            # inference: the candidate selection reads the heads' convolution outputs where they are
+            maps = self.head.forward_maps(features)
+            anchors = self.anchor_generator(images, features)
+            num_classes = self.head.classification_head.num_classes
+            per_level = [m.shape[1] // num_classes * m.shape[2] * m.shape[3] for m in maps["cls_logits"]]
+            split_anchors = [list(a.split(per_level)) for a in anchors]
+            detections = postprocess_batched(maps["cls_logits"], maps["bbox_regression"], split_anchors,
+                                             images.image_sizes, self.score_thresh, self.topk_candidates,
+                                             self.nms_thresh, self.detections_per_img, _C.CODER_LINEAR, 0.0,
+                                             ctr_levels=maps["bbox_ctrness"], planar_classes=num_classes)
+            return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
         head_outputs = self.head(features)
         anchors = self.anchor_generator(images, features)
         num_anchors_per_level = [x.size(2) * x.size(3) * self.anchor_generator.num_anchors_per_location()[0]

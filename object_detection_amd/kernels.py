@@ -266,6 +266,67 @@ def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor]
     return cand_boxes, cand_scores, cand_labels, cand_index, cand_count
 
 
+def select_candidates_planar(cls_maps: Sequence[Tensor], reg_maps: Sequence[Tensor], anchor_levels: Sequence[Tensor],
+                             image_hw: Tensor, num_classes: int, score_thresh: float, topk: int, coder: int,
+                             bbox_xform_clip: float, ctr_maps: Optional[Sequence[Tensor]] = None,
+                             want_index: bool = False):
+    """select_candidates on the head's convolution outputs as they are: cls_maps[l] [B, A*C, H, W],
+    reg_maps[l] [B, A*4, H, W], ctr_maps[l] [B, A, H, W] (FCOS); anchor_levels[l] [H*W*A, 4] in (y, x, a) order.
+    Results are those of select_candidates on the permuted [B, H*W*A, .] tensors; the permute copy is not made."""
+    L = len(cls_maps)
+    dev = cls_maps[0].device
+    _require_gpu(cls_maps[0], "cls_logits")
+    B, C = cls_maps[0].shape[0], int(num_classes)
+    planes = [int(t.shape[2] * t.shape[3]) for t in cls_maps]
+    sizes = [int(t.shape[1]) // C * pl for t, pl in zip(cls_maps, planes)]
+    key = (dev.index, tuple(sizes), B, C)
+    plan = _plans.get(key)
+    if plan is None:
+        plan = _plans[key] = SelectPlan(sizes, B, C, dev)
+
+    def dense(maps, per_anchor):
+        out = []
+        for t, n, pl in zip(maps, sizes, planes):
+            if t.dtype is not torch.float32:
+                t = t.float()
+            t = t.contiguous()                               # plain NCHW (a channels_last tensor is copied here)
+            if t.shape[0] != B or t.shape[1] * pl != n * per_anchor:
+                raise ValueError(f"head output of shape {tuple(t.shape)} does not hold {n} anchors x {per_anchor}")
+            out.append(t)
+        return out
+
+    cls_t, reg_t = dense(cls_maps, C), dense(reg_maps, 4)
+    ctr_t = dense(ctr_maps, 1) if ctr_maps is not None else None
+    anc_t, anc_s = [], []
+    for a, n in zip(anchor_levels, sizes):
+        if a.dtype is not torch.float32:
+            a = a.float()
+        a = a.contiguous()
+        if a.shape[-2] != n:
+            raise ValueError(f"{a.shape[-2]} anchors for a level of {n}")
+        anc_t.append(a)
+        anc_s.append(a.stride(0) if a.dim() == 3 else 0)
+    K = int(topk)
+    cand_boxes = torch.empty((B, L * K, 4), dtype=torch.float32, device=dev)
+    cand_scores = torch.empty((B, L * K), dtype=torch.float32, device=dev)
+    cand_labels = torch.empty((B, L * K), dtype=torch.int32, device=dev)
+    cand_index = torch.empty((B, L * K), dtype=torch.int64, device=dev) if want_index else None
+    cand_count = torch.empty((B, L), dtype=torch.int32, device=dev)
+    ws = _workspace(dev, "select", plan.ws_bytes)
+    P, I64 = plan.P, plan.I64
+    rc = _C.lib().od_select_candidates_planar(
+        P(*[t.data_ptr() for t in cls_t]), I64(*[t.stride(0) for t in cls_t]),
+        P(*[t.data_ptr() for t in ctr_t]) if ctr_t is not None else None,
+        I64(*[t.stride(0) for t in ctr_t]) if ctr_t is not None else None,
+        P(*[t.data_ptr() for t in reg_t]), I64(*[t.stride(0) for t in reg_t]),
+        P(*[t.data_ptr() for t in anc_t]), I64(*anc_s),
+        plan.sizes, I64(*planes), L, B, C, _ptr(image_hw), float(score_thresh), K, int(coder), float(bbox_xform_clip),
+        _ptr(cand_boxes), _ptr(cand_scores), _ptr(cand_labels), _ptr(cand_index), _ptr(cand_count),
+        _ptr(ws), ws.numel(), _stream(dev))
+    _C.check(rc, "od_select_candidates_planar")
+    return cand_boxes, cand_scores, cand_labels, cand_index, cand_count
+
+
 def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], seg_count: Tensor, seg_stride: int,
                        segments_sorted: bool, iou_threshold: float, mode: int, max_keep: int,
                        want_keep_idx: bool = True, want_labels: bool = True):

@@ -84,8 +84,12 @@ class RetinaNetClassificationHead(nn.Module):
                           / max(1, num_fg))
         return _sum(losses) / len(targets)
 
+    def forward_maps(self, x: List[Tensor]) -> List[Tensor]:
+        """Per-level convolution outputs [B, A*C, H, W], before the permute + reshape of ``forward``."""
+        return [self.cls_logits(self.conv(f)) for f in x]
+
     def forward(self, x: List[Tensor]) -> Tensor:
-        return torch.cat([_to_anchor_major(self.cls_logits(self.conv(f)), self.num_classes) for f in x], dim=1)
+        return torch.cat([_to_anchor_major(m, self.num_classes) for m in self.forward_maps(x)], dim=1)
 
 
 class RetinaNetRegressionHead(nn.Module):
@@ -113,8 +117,12 @@ class RetinaNetRegressionHead(nn.Module):
                                               reg[fg, :]) / max(1, num_fg))
         return _sum(losses) / max(1, len(targets))
 
+    def forward_maps(self, x: List[Tensor]) -> List[Tensor]:
+        """Per-level convolution outputs [B, A*4, H, W], before the permute + reshape of ``forward``."""
+        return [self.bbox_reg(self.conv(f)) for f in x]
+
     def forward(self, x: List[Tensor]) -> Tensor:
-        return torch.cat([_to_anchor_major(self.bbox_reg(self.conv(f)), 4) for f in x], dim=1)
+        return torch.cat([_to_anchor_major(m, 4) for m in self.forward_maps(x)], dim=1)
 
 
 class RetinaNetHead(nn.Module):
@@ -132,6 +140,12 @@ class RetinaNetHead(nn.Module):
 
     def forward(self, x: List[Tensor]) -> Dict[str, Tensor]:
         return {"cls_logits": self.classification_head(x), "bbox_regression": self.regression_head(x)}
+
+    def forward_maps(self, x: List[Tensor]) -> Dict[str, List[Tensor]]:
+        """Head outputs per level in the convolutions' own channel-major layout (inference path: the candidate
+        selection reads them in place instead of the permuted copies ``forward`` makes)."""
+        return {"cls_logits": self.classification_head.forward_maps(x),
+                "bbox_regression": self.regression_head.forward_maps(x)}
 
 
 def _shared_levels(anchors: List[List[Tensor]]) -> Optional[List[Tensor]]:
@@ -153,16 +167,22 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
 
 def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,
                         detections_per_img, coder, bbox_xform_clip, ctr_levels=None, nms_mode=_C.NMS_AUTO_GPU,
-                        return_padded: bool = False):
-    """Shared tail of RetinaNet / FCOS postprocess_detections: two library calls for the whole batch."""
+                        return_padded: bool = False, planar_classes: Optional[int] = None):
+    """Shared tail of RetinaNet / FCOS postprocess_detections: two library calls for the whole batch.
+    With ``planar_classes`` (= number of classes) the level tensors are the heads' convolution outputs
+    [B, A*K, H, W] instead of the permuted [B, H*W*A, K]."""
     shared = _shared_levels(anchors)
     if shared is None:
         shared = [torch.stack([a[l] for a in anchors]) for l in range(len(anchors[0]))]
     dev = cls_levels[0].device
     hw = _image_hw_tensor(image_shapes, dev)
     K = int(topk_candidates)
-    cb, cs, cl, _, cc = kernels.select_candidates(cls_levels, reg_levels, shared, hw, score_thresh, K, coder,
-                                                  bbox_xform_clip, ctr_levels=ctr_levels)
+    if planar_classes is not None:
+        cb, cs, cl, _, cc = kernels.select_candidates_planar(cls_levels, reg_levels, shared, hw, planar_classes,
+                                                             score_thresh, K, coder, bbox_xform_clip, ctr_maps=ctr_levels)
+    else:
+        cb, cs, cl, _, cc = kernels.select_candidates(cls_levels, reg_levels, shared, hw, score_thresh, K, coder,
+                                                      bbox_xform_clip, ctr_levels=ctr_levels)
     _, ob, os_, ol, oc = kernels.batched_nms_padded(cb, cs, cl, cc, K, True, nms_thresh, nms_mode,
                                                     int(detections_per_img), want_keep_idx=False)
     if return_padded:
@@ -266,6 +286,19 @@ class RetinaNet(nn.Module):
         if isinstance(features, torch.Tensor):
             features = OrderedDict([("0", features)])
         features = list(features.values())
+        if (not self.training and features[0].is_cuda and hasattr(self.head, "forward_maps")
+                and type(self).postprocess_detections is RetinaNet.postprocess_detections):
+            # inference: the candidate selection reads the heads' convolution outputs where they are
+            maps = self.head.forward_maps(features)
+            anchors = self.anchor_generator(images, features)
+            num_classes = self.head.classification_head.num_classes
+            per_level = [m.shape[1] // num_classes * m.shape[2] * m.shape[3] for m in maps["cls_logits"]]
+            split_anchors = [list(a.split(per_level)) for a in anchors]
+            detections = postprocess_batched(maps["cls_logits"], maps["bbox_regression"], split_anchors,
+                                             images.image_sizes, self.score_thresh, self.topk_candidates,
+                                             self.nms_thresh, self.detections_per_img, _C.CODER_BOXCODER,
+                                             self.box_coder.bbox_xform_clip, planar_classes=num_classes)
+            return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
         head_outputs = self.head(features)
         anchors = self.anchor_generator(images, features)
         losses: Dict[str, Tensor] = {}

@@ -415,3 +415,38 @@ def test_box_loss_kernels(device, loss_type, n, shared_anchors):
     assert torch.equal(grad[matched < 0], torch.zeros_like(grad[matched < 0]))
     if loss_type == "giou":
         assert float(grad[0, ::97, 2].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("num_anchors,num_classes,with_ctr", [(9, 4, False), (3, 91, False), (1, 5, True), (2, 3, True)])
+def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors, num_classes, with_ctr):
+    """od_select_candidates_planar on the convolution layout [B, A*K, H, W] returns exactly what
+    od_select_candidates returns on the permuted [B, H*W*A, K] copies (boxes, scores, labels, flat indices, counts),
+    for square and ragged planes, chunks that end inside a plane and planes smaller than a chunk."""
+    g = torch.Generator().manual_seed(77 + num_anchors + num_classes)
+    B, K = 3, 200
+    planes = [(48, 40), (17, 23), (6, 5), (1, 1)]
+    A, C = num_anchors, num_classes
+
+    def permuted(m, per_anchor):
+        b, _, h, w = m.shape
+        return m.view(b, -1, per_anchor, h, w).permute(0, 3, 4, 1, 2).reshape(b, -1, per_anchor)
+
+    cls_maps, reg_maps, ctr_maps, anchors = [], [], [], []
+    for h, w in planes:
+        cls_maps.append((torch.randn((B, A * C, h, w), generator=g) * 1.5 - 1.0).to(device))
+        reg = torch.randn((B, A * 4, h, w), generator=g) * 0.5
+        reg_maps.append((reg.abs() if with_ctr else reg).to(device))
+        ctr_maps.append(torch.randn((B, A, h, w), generator=g).to(device))
+        anchors.append(_random_boxes(g, h * w * A, extent=400.0).to(device))
+    hw = torch.tensor([[500, 480], [400, 500], [512, 512]], dtype=torch.int32, device=device)
+    coder = _C.CODER_LINEAR if with_ctr else _C.CODER_BOXCODER
+    want = kernels.select_candidates([permuted(m, C) for m in cls_maps], [permuted(m, 4) for m in reg_maps], anchors, hw,
+                                     0.3, K, coder, 4.135, want_index=True,
+                                     ctr_levels=[permuted(m, 1) for m in ctr_maps] if with_ctr else None)
+    got = kernels.select_candidates_planar(cls_maps, reg_maps, anchors, hw, C, 0.3, K, coder, 4.135, want_index=True,
+                                           ctr_maps=ctr_maps if with_ctr else None)
+    counts = want[4].cpu()
+    assert torch.equal(got[4].cpu(), counts) and int(counts.sum()) > 0
+    valid = (torch.arange(K)[None, None, :] < counts[:, :, None]).reshape(B, -1)
+    for a, b, name in zip(got[:4], want[:4], ("boxes", "scores", "labels", "index")):
+        assert torch.equal(a.cpu()[valid], b.cpu()[valid]), name

@@ -162,6 +162,34 @@ def test_forward_end_to_end_shapes(device):
         assert (d["scores"][:-1] >= d["scores"][1:]).all()
 
 
+@pytest.mark.parametrize("arch", ["retinanet", "fcos"])
+def test_eval_forward_reads_head_maps_in_place(device, arch):
+    """model(images) in eval mode takes the channel-major route (no permuted copies of the head outputs) and returns
+    exactly the detections of the torchvision-shaped route: head.forward -> split -> postprocess_detections."""
+    torch.manual_seed(3)
+    kw = dict(backbone="pyramid_stub", out_channels=32, min_size=160, max_size=160, score_thresh=0.005, nms_thresh=0.4,
+              detections_per_img=60)
+    model = (get_model(4, layers=[0, 1], **kw) if arch == "retinanet" else get_model(4, arch="fcos", **kw)).to(device).eval()
+    images = [torch.rand(3, 160, 160, device=device), torch.rand(3, 120, 150, device=device)]
+    with torch.no_grad():
+        dets = model(images)
+        # the same through the public pieces, as torchvision's forward strings them together
+        sizes = [(int(i.shape[-2]), int(i.shape[-1])) for i in images]
+        il, _ = model.transform(images, None)
+        feats = list(model.backbone(il.tensors).values())
+        out = model.head(feats)
+        anchors = model.anchor_generator(il, feats)
+        per_level = [f.shape[2] * f.shape[3] * (out["cls_logits"].shape[1] // sum(x.shape[2] * x.shape[3] for x in feats))
+                     for f in feats]
+        split = {k: list(v.split(per_level, dim=1)) for k, v in out.items()}
+        ref = model.postprocess_detections(split, [list(a.split(per_level)) for a in anchors], il.image_sizes)
+        ref = model.transform.postprocess(ref, il.image_sizes, sizes)
+    assert sum(d["boxes"].shape[0] for d in dets) > 0
+    for d, r in zip(dets, ref):
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(d[k], r[k]), k
+
+
 def test_compute_loss_matches_checker(device):
     cfg = dataclasses.replace(synthetic.CFG1, num_gt=30)
     model = _model(cfg, device)

@@ -84,6 +84,25 @@ def main():
         K = cfg.topk_candidates
         sel = lambda: kernels.select_candidates(cls_l, reg_l, anc_l, hw, cfg.score_thresh, K, _C.CODER_BOXCODER, 4.135)
         res["select"] = timed(sel)
+        A = 9
+
+        def to_maps(levels, per_anchor):      # [B, g*g*A, k] -> the convolution layout [B, A*k, g, g]
+            return [t.view(cfg.batch, g, g, A, per_anchor).permute(0, 3, 4, 1, 2).reshape(cfg.batch, A * per_anchor, g, g)
+                    .contiguous() for t, g in zip(levels, cfg.grids)]
+
+        cls_m, reg_m = to_maps(cls_l, cls.shape[-1]), to_maps(reg_l, 4)
+        res["select_planar"] = timed(lambda: kernels.select_candidates_planar(
+            cls_m, reg_m, anc_l, hw, cls.shape[-1], cfg.score_thresh, K, _C.CODER_BOXCODER, 4.135))
+        pl = kernels.select_candidates_planar(cls_m, reg_m, anc_l, hw, cls.shape[-1], cfg.score_thresh, K,
+                                              _C.CODER_BOXCODER, 4.135)
+        res["planar_equal"] = all(bool(torch.equal(a, b)) for a, b in zip(pl[:3] + pl[4:], sel()[:3] + sel()[4:]))
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(10):
+            [m.view(cfg.batch, A, -1, g, g).permute(0, 3, 4, 1, 2).reshape(cfg.batch, -1, m.shape[1] // A)
+             for m, g in zip(cls_m + reg_m, cfg.grids + cfg.grids)]
+        t1.record(); torch.cuda.synchronize()
+        res["permute_copies_us"] = round(t0.elapsed_time(t1) * 100.0, 1)
         cb, cs, cl, _, cc = sel()
         res["cand_per_image"] = float(cc.sum().item()) / cfg.batch
         for mk in (1, 100, 500, 6000):
