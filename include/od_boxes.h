@@ -229,6 +229,22 @@ int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, con
                          float* grad_regression, void* stream);
 
 /*
+ * Image side of the model's input transform in one pass.  Replaces torchvision GeneralizedRCNNTransform.forward's
+ * normalize -> resize (torch.nn.functional.interpolate, bilinear, align_corners=False, recompute_scale_factor=True)
+ * -> batch_images (zero padding); the reference configures it through get_model(min_size=size, max_size=size)
+ * (reference train.py:142-144).
+ *   images[i]   : host array of device pointers, image i fp32 [channels, image_h[i], image_w[i]] contiguous
+ *   resized_h/w : host int32, size of image i after the resize (chosen by the caller exactly as torchvision does)
+ *   mean, std   : host float [channels], channels <= 4
+ *   out         : fp32 [batch, channels, out_h, out_w]; image i occupies the top-left resized_h[i] x resized_w[i]
+ *                 corner, the rest is written as zero
+ * Floating point: every operation rounded separately in the order of the torch evaluation; tests use 1e-5.
+ */
+int od_preprocess_images(const float* const* images, const int32_t* image_h, const int32_t* image_w,
+                         const int32_t* resized_h, const int32_t* resized_w, int32_t batch, int32_t channels,
+                         const float* mean, const float* std, float* out, int32_t out_h, int32_t out_w, void* stream);
+
+/*
  * Per-kernel timing aid.  No counterpart in the reference (it has no profiling hooks); used by
  * bench.py to measure a kernel's own duration on the stream it runs on.  od_profile_select makes the
  * library bracket every later launch of that kernel (or of all kernels) with hipEvents;
@@ -253,7 +269,8 @@ int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, con
 #define OD_KERNEL_FOCAL_BWD 13
 #define OD_KERNEL_BOX_LOSS_FWD 14   /* od_box_loss_forward: the streaming kernel                 */
 #define OD_KERNEL_BOX_LOSS_BWD 15
-#define OD_KERNEL_COUNT 16
+#define OD_KERNEL_PREPROCESS 16
+#define OD_KERNEL_COUNT 17
 int od_profile_select(int32_t kernel_id);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 

@@ -58,13 +58,14 @@ SIGNATURES = {
                                       c_float, c_float, _P, _P, _P, _P, c_size_t, _P]),
     "od_box_loss_backward": (c_int32, [_P, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int32, c_int32, c_float, _P,
                                        c_float, c_float, _P, _P, _P, _P]),
+    "od_preprocess_images": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "od_profile_select": (c_int32, [c_int32]),
     "od_profile_read": (c_int32, [c_int32, _P, _P]),
 }
 
 PROFILE_OFF, PROFILE_ALL = -1, -2
 KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
-                "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd"]
+                "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 
 _lib = None

@@ -206,7 +206,8 @@ class FCOS(nn.Module):
             features = OrderedDict([("0", features)])
         features = list(features.values())
         if (not self.training and features[0].is_cuda and hasattr(self.head, "forward_maps")
-                and type(self).postprocess_detections is FCOS.postprocess_detections):
+                and type(self).postprocess_detections is FCOS.postprocess_detections
+                and type(self.transform) is GeneralizedRCNNTransform):
             # inference: the candidate selection reads the heads' convolution outputs where they are
             maps = self.head.forward_maps(features)
             anchors = self.anchor_generator(images, features)
@@ -216,8 +217,10 @@ class FCOS(nn.Module):
             detections = postprocess_batched(maps["cls_logits"], maps["bbox_regression"], split_anchors,
                                              images.image_sizes, self.score_thresh, self.topk_candidates,
                                              self.nms_thresh, self.detections_per_img, _C.CODER_LINEAR, 0.0,
-                                             ctr_levels=maps["bbox_ctrness"], planar_classes=num_classes)
-            return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
+                                             ctr_levels=maps["bbox_ctrness"], planar_classes=num_classes,
+                                             box_scale=self.transform.box_scales(images.image_sizes, original_image_sizes,
+                                                                                 features[0].device))
+            return detections
         head_outputs = self.head(features)
         anchors = self.anchor_generator(images, features)
         num_anchors_per_level = [x.size(2) * x.size(3) * self.anchor_generator.num_anchors_per_location()[0]

@@ -63,6 +63,18 @@ def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32)
     return t
 
 
+def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
+    """Small host tuple of floats -> fp32 device tensor, cached by value."""
+    key = (device.index, "f32", tuple(float(v) for v in values))
+    t = _small_cache.get(key)
+    if t is None:
+        if len(_small_cache) > 4096:
+            _small_cache.clear()
+        t = torch.tensor(list(key[2]), dtype=torch.float32, device=device)
+        _small_cache[key] = t
+    return t
+
+
 # ------------------------------------------------------------------------------------------------
 def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tuple[int, int]],
                     cell_anchors: Sequence[Tensor], device: torch.device) -> Tensor:
@@ -431,3 +443,23 @@ def box_loss_backward(bbox_regression: Tensor, anchors: Tensor, matched: Tensor,
     rc = _C.lib().od_box_loss_backward(*args, _ptr(num_fg), _ptr(grad_loss), _ptr(grad), _stream(dev))
     _C.check(rc, "od_box_loss_backward")
     return grad
+
+
+def preprocess_images(images: Sequence[Tensor], resized: Sequence[Tuple[int, int]], mean: Sequence[float],
+                      std: Sequence[float], out_hw: Tuple[int, int]) -> Tensor:
+    """Normalize + bilinear resize + zero-padded batch in one pass.  images[i]: fp32 [C, h_i, w_i] on the GPU;
+    resized[i]: (height, width) of image i after the resize; returns fp32 [B, C, out_hw[0], out_hw[1]]."""
+    _require_gpu(images[0], "images")
+    dev = images[0].device
+    B, C = len(images), int(images[0].shape[0])
+    imgs = [im if im.is_contiguous() else im.contiguous() for im in images]
+    I32 = ctypes.c_int32 * B
+    F = ctypes.c_float * C
+    out = torch.empty((B, C, int(out_hw[0]), int(out_hw[1])), dtype=torch.float32, device=dev)
+    rc = _C.lib().od_preprocess_images(
+        (ctypes.c_void_p * B)(*[im.data_ptr() for im in imgs]), I32(*[int(im.shape[1]) for im in imgs]),
+        I32(*[int(im.shape[2]) for im in imgs]), I32(*[int(r[0]) for r in resized]), I32(*[int(r[1]) for r in resized]),
+        B, C, F(*[float(m) for m in mean]), F(*[float(v) for v in std]), _ptr(out), int(out_hw[0]), int(out_hw[1]),
+        _stream(dev))
+    _C.check(rc, "od_preprocess_images")
+    return out

@@ -167,10 +167,12 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
 
 def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,
                         detections_per_img, coder, bbox_xform_clip, ctr_levels=None, nms_mode=_C.NMS_AUTO_GPU,
-                        return_padded: bool = False, planar_classes: Optional[int] = None):
+                        return_padded: bool = False, planar_classes: Optional[int] = None,
+                        box_scale: Optional[Tensor] = None):
     """Shared tail of RetinaNet / FCOS postprocess_detections: two library calls for the whole batch.
     With ``planar_classes`` (= number of classes) the level tensors are the heads' convolution outputs
-    [B, A*K, H, W] instead of the permuted [B, H*W*A, K]."""
+    [B, A*K, H, W] instead of the permuted [B, H*W*A, K].  ``box_scale`` [B, 4] multiplies the kept boxes of each image
+    (the rescale of ``transform.postprocess``)."""
     shared = _shared_levels(anchors)
     if shared is None:
         shared = [torch.stack([a[l] for a in anchors]) for l in range(len(anchors[0]))]
@@ -185,6 +187,8 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
                                                       bbox_xform_clip, ctr_levels=ctr_levels)
     _, ob, os_, ol, oc = kernels.batched_nms_padded(cb, cs, cl, cc, K, True, nms_thresh, nms_mode,
                                                     int(detections_per_img), want_keep_idx=False)
+    if box_scale is not None:
+        ob = ob * box_scale[:, None, :]
     if return_padded:
         return ob, os_, ol, oc
     counts = oc.tolist()   # the one device->host read: detections are variable-length tensors
@@ -287,7 +291,8 @@ class RetinaNet(nn.Module):
             features = OrderedDict([("0", features)])
         features = list(features.values())
         if (not self.training and features[0].is_cuda and hasattr(self.head, "forward_maps")
-                and type(self).postprocess_detections is RetinaNet.postprocess_detections):
+                and type(self).postprocess_detections is RetinaNet.postprocess_detections
+                and type(self.transform) is GeneralizedRCNNTransform):
             # inference: the candidate selection reads the heads' convolution outputs where they are
             maps = self.head.forward_maps(features)
             anchors = self.anchor_generator(images, features)
@@ -297,8 +302,10 @@ class RetinaNet(nn.Module):
             detections = postprocess_batched(maps["cls_logits"], maps["bbox_regression"], split_anchors,
                                              images.image_sizes, self.score_thresh, self.topk_candidates,
                                              self.nms_thresh, self.detections_per_img, _C.CODER_BOXCODER,
-                                             self.box_coder.bbox_xform_clip, planar_classes=num_classes)
-            return self.transform.postprocess(detections, images.image_sizes, original_image_sizes)
+                                             self.box_coder.bbox_xform_clip, planar_classes=num_classes,
+                                             box_scale=self.transform.box_scales(images.image_sizes, original_image_sizes,
+                                                                                 features[0].device))
+            return detections
         head_outputs = self.head(features)
         anchors = self.anchor_generator(images, features)
         losses: Dict[str, Tensor] = {}

@@ -450,3 +450,33 @@ def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors,
     valid = (torch.arange(K)[None, None, :] < counts[:, :, None]).reshape(B, -1)
     for a, b, name in zip(got[:4], want[:4], ("boxes", "scores", "labels", "index")):
         assert torch.equal(a.cpu()[valid], b.cpu()[valid]), name
+
+
+@pytest.mark.parametrize("min_size,max_size,shapes", [
+    (160, 160, [(160, 160), (160, 160)]),                         # already at size: the resize is the identity
+    (192, 256, [(120, 150), (300, 200), (97, 131)]),              # up- and down-scaling, ragged, padding
+    (64, 100, [(401, 37), (64, 64)]),                             # max_size caps the scale
+])
+def test_preprocess_images_matches_torch_transform(device, min_size, max_size, shapes):
+    """Fused normalize + bilinear resize + padded batch against the same steps as torch ops on the CPU
+    (normalize -> interpolate(bilinear, align_corners=False, recompute_scale_factor=True) -> batch_images):
+    1e-5 absolute + 1e-5 relative on the pixels, identical sizes, padding exactly zero, target boxes identical."""
+    from object_detection_amd.transform import GeneralizedRCNNTransform
+    g = torch.Generator().manual_seed(min_size + len(shapes))
+    tr = GeneralizedRCNNTransform(min_size, max_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    images = [torch.rand((3, h, w), generator=g) for h, w in shapes]
+    targets = [{"boxes": _random_boxes(g, 5, extent=50.0), "labels": torch.ones(5, dtype=torch.int64)} for _ in shapes]
+    ref, ref_t = tr(images, targets)                                # CPU tensors: torch ops
+    got, got_t = tr([im.to(device) for im in images], [{k: v.to(device) for k, v in t.items()} for t in targets])
+    assert got.image_sizes == ref.image_sizes
+    assert got.tensors.shape == ref.tensors.shape
+    diff = (got.tensors.cpu() - ref.tensors).abs()
+    assert bool((diff <= 1e-5 + 1e-5 * ref.tensors.abs()).all()), float(diff.max())
+    for i, (h, w) in enumerate(ref.image_sizes):
+        assert float(got.tensors[i, :, h:, :].abs().max() if h < got.tensors.shape[2] else 0.0) == 0.0
+        assert float(got.tensors[i, :, :, w:].abs().max() if w < got.tensors.shape[3] else 0.0) == 0.0
+    for a, b in zip(got_t, ref_t):
+        assert torch.equal(a["boxes"].cpu(), b["boxes"])
+    if shapes[0] == (160, 160):
+        want = (images[0] - torch.tensor(tr.image_mean)[:, None, None]) / torch.tensor(tr.image_std)[:, None, None]
+        assert torch.equal(got.tensors[0].cpu(), want)              # identity resize: the normalized pixels themselves

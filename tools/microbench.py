@@ -144,6 +144,22 @@ def main():
         E = cls.numel()
         res["loss_GBps"] = {"focal_fwd": (4 * E + 8 * matched.numel()) / (res["loss"]["focal_fwd"] * 1e-6) / 1e9,
                             "focal_bwd": (8 * E + 8 * matched.numel()) / (res["loss"]["focal_bwd"] * 1e-6) / 1e9}
+    if args.what in ("all", "pre"):
+        from object_detection_amd.transform import GeneralizedRCNNTransform
+        tr = GeneralizedRCNNTransform(1024, 1024, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+        for name, shape in (("identity_1024", (1024, 1024)), ("resize_from_720x960", (720, 960))):
+            imgs = [torch.rand((3,) + shape, device=dev) for _ in range(cfg.batch)]
+            res["pre_" + name] = timed(lambda: tr(imgs))
+            t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0.record()
+            for _ in range(5):
+                out = []
+                for im in imgs:
+                    out.append(tr.resize(tr.normalize(im), None)[0])
+                tr.batch_images(out)
+            t1.record(); torch.cuda.synchronize()
+            res["pre_" + name + "_torch_ops_us"] = round(t0.elapsed_time(t1) * 200.0, 1)
     if os.environ.get("OD_STAMPS"):
         kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh, _C.NMS_AUTO_GPU, 500, want_keep_idx=False)
         torch.cuda.synchronize()
