@@ -362,7 +362,7 @@ def test_focal_loss_kernels_class_counts_and_ragged_sizes(device, num_classes, n
         assert torch.equal(grad[matched == -2], torch.zeros_like(grad[matched == -2]))
 
 
-def _random_boxes(gen, count, extent=900.0):
+def _uniform_boxes(gen, count, extent=900.0):
     xy = torch.rand((count, 2), generator=gen) * extent
     wh = 8.0 + torch.rand((count, 2), generator=gen) * 192.0
     return torch.cat([xy, xy + wh], dim=1)
@@ -380,8 +380,8 @@ def test_box_loss_kernels(device, loss_type, n, shared_anchors):
     g = torch.Generator().manual_seed(4000 + n + len(loss_type))
     B, M = 3, 11
     weights = (1.0, 1.0, 1.0, 1.0) if loss_type == "giou" else (10.0, 10.0, 5.0, 5.0)
-    anchors = _random_boxes(g, n) if shared_anchors else torch.stack([_random_boxes(g, n) for _ in range(B)])
-    gt = [_random_boxes(g, M) for _ in range(B)]
+    anchors = _uniform_boxes(g, n) if shared_anchors else torch.stack([_uniform_boxes(g, n) for _ in range(B)])
+    gt = [_uniform_boxes(g, M) for _ in range(B)]
     matched = torch.randint(-2, M, (B, n), generator=g)
     matched[2] = torch.where(matched[2] >= 0, torch.full_like(matched[2], -1), matched[2])
     # anchors matched to a target overlap it in a typical way: target = anchor moved and scaled a little
@@ -437,7 +437,7 @@ def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors,
         reg = torch.randn((B, A * 4, h, w), generator=g) * 0.5
         reg_maps.append((reg.abs() if with_ctr else reg).to(device))
         ctr_maps.append(torch.randn((B, A, h, w), generator=g).to(device))
-        anchors.append(_random_boxes(g, h * w * A, extent=400.0).to(device))
+        anchors.append(_uniform_boxes(g, h * w * A, extent=400.0).to(device))
     hw = torch.tensor([[500, 480], [400, 500], [512, 512]], dtype=torch.int32, device=device)
     coder = _C.CODER_LINEAR if with_ctr else _C.CODER_BOXCODER
     want = kernels.select_candidates([permuted(m, C) for m in cls_maps], [permuted(m, 4) for m in reg_maps], anchors, hw,
@@ -465,7 +465,7 @@ def test_preprocess_images_matches_torch_transform(device, min_size, max_size, s
     g = torch.Generator().manual_seed(min_size + len(shapes))
     tr = GeneralizedRCNNTransform(min_size, max_size, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
     images = [torch.rand((3, h, w), generator=g) for h, w in shapes]
-    targets = [{"boxes": _random_boxes(g, 5, extent=50.0), "labels": torch.ones(5, dtype=torch.int64)} for _ in shapes]
+    targets = [{"boxes": _uniform_boxes(g, 5, extent=50.0), "labels": torch.ones(5, dtype=torch.int64)} for _ in shapes]
     ref, ref_t = tr(images, targets)                                # CPU tensors: torch ops
     got, got_t = tr([im.to(device) for im in images], [{k: v.to(device) for k, v in t.items()} for t in targets])
     assert got.image_sizes == ref.image_sizes
