@@ -183,22 +183,27 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
  * / max(1, #foreground), averaged over the batch (head built at reference retinanet_model.py:47-54, loss taken at
  * train.py:62-63).  target[a, c] = 1 iff matched[a] >= 0 and gt_labels[matched[a]] == c; anchors with
  * matched == -2 are ignored.
- *   cls_logits : fp32 [batch, n, num_classes], images batch_stride elements apart
+ *   cls_logits : [batch, n, num_classes] of element type `dtype` (OD_DTYPE_*: fp32, or the fp16 / bf16 a head
+ *                produces under autocast -- the reference trains with use_amp, config_all.py:16, train.py:61),
+ *                images batch_stride elements apart; arithmetic is fp32 for every element type
  *   matched    : int64 [batch, n] as written by od_match_retinanet;  gt_labels: int64 [gt_offsets[batch]]
  *   forward  -> loss fp32 [1] (mean over images), per_image_loss fp32 [batch], num_foreground int32 [batch]
- *   backward -> grad_logits fp32 [batch, n, num_classes] (contiguous) = grad_loss[0] * d loss / d cls_logits,
- *               from the forward's num_foreground
+ *   backward -> grad_logits [batch, n, num_classes] of the same element type (contiguous; 16-bit values rounded once,
+ *               to nearest even) = grad_loss[0] * d loss / d cls_logits, from the forward's num_foreground
  * Floating point: agrees with the fp32 torch evaluation to about 1e-6 relative (tests use 1e-5).
  */
+#define OD_DTYPE_F32 0
+#define OD_DTYPE_F16 1          /* IEEE half    */
+#define OD_DTYPE_BF16 2         /* bfloat16     */
 size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, int32_t batch);
-int od_focal_loss_forward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                           const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
                           float alpha, float gamma, float* loss, float* per_image_loss, int32_t* num_foreground,
                           void* workspace, size_t workspace_bytes, void* stream);
-int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                            const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
                            float alpha, float gamma, const int32_t* num_foreground, const float* grad_loss,
-                           float* grad_logits, void* stream);
+                           void* grad_logits, void* stream);
 
 /*
  * Regression loss of the RetinaNet head.  Replaces torchvision RetinaNetRegressionHead.compute_loss =
@@ -206,27 +211,29 @@ int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_
  * foreground anchors fg = matched >= 0, averaged over the batch.  The reference selects type "giou"
  * (reference retinanet_model.py:53: generalized_box_iou_loss of the decoded boxes, eps = fp32 machine epsilon);
  * "l1" (torchvision's default) and "smooth_l1" compare the regression with BoxCoder.encode_single(gt, anchor).
- *   bbox_regression: fp32 [batch, n, 4], images batch_stride elements apart (16-byte aligned rows)
+ *   bbox_regression: [batch, n, 4] of element type `dtype` (OD_DTYPE_*), images batch_stride elements apart, rows
+ *                    aligned to four elements; arithmetic is fp32
  *   anchors        : fp32 [n, 4]; images anchor_batch_stride elements apart, 0 = one table shared by all images
  *   matched        : int64 [batch, n];  gt_boxes: fp32 [gt_offsets[batch], 4];  weights: 4 host floats (BoxCoder)
  *   forward  -> loss fp32 [1], per_image_loss fp32 [batch], num_foreground int32 [batch]
- *   backward -> grad_regression fp32 [batch, n, 4] (contiguous; zero rows for anchors that are not foreground)
+ *   backward -> grad_regression [batch, n, 4] of the same element type (contiguous; zero rows for anchors that are
+ *               not foreground)
  * Floating point: fp32 in the operation order of the torch evaluation; tests use 1e-5 relative.
  */
 #define OD_BOX_LOSS_L1 0
 #define OD_BOX_LOSS_SMOOTH_L1 1
 #define OD_BOX_LOSS_GIOU 2
 size_t od_box_loss_workspace_bytes(int64_t n, int32_t batch);
-int od_box_loss_forward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+int od_box_loss_forward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
                         int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
                         const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta, const float* weights,
                         float bbox_xform_clip, float eps, float* loss, float* per_image_loss, int32_t* num_foreground,
                         void* workspace, size_t workspace_bytes, void* stream);
-int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+int od_box_loss_backward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
                          int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
                          const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta, const float* weights,
                          float bbox_xform_clip, float eps, const int32_t* num_foreground, const float* grad_loss,
-                         float* grad_regression, void* stream);
+                         void* grad_regression, void* stream);
 
 /*
  * Image side of the model's input transform in one pass.  Replaces torchvision GeneralizedRCNNTransform.forward's

@@ -29,6 +29,42 @@ constexpr int LCHUNK = LT * LPT;        // elements per workgroup
 
 typedef float vec4f __attribute__((ext_vector_type(4)));
 
+// Element types of the head outputs and of their gradients: fp32, or the 16-bit types a head produces under autocast
+// (the reference trains with use_amp, reference object_detection/configs/config_all.py:16, train.py:61).  All
+// arithmetic is fp32; a 16-bit gradient is rounded once, to nearest even.
+struct bf16_t { unsigned short bits; };
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    typedef vec4f V;
+    static __device__ __forceinline__ float to_float(float v) { return v; }
+    static __device__ __forceinline__ float from_float(float v) { return v; }
+    static __device__ __forceinline__ float4 unpack(V v) { return make_float4(v.x, v.y, v.z, v.w); }
+    static __device__ __forceinline__ V pack(float4 f) { V v; v.x = f.x; v.y = f.y; v.z = f.z; v.w = f.w; return v; }
+};
+template <> struct Elem<_Float16> {
+    typedef _Float16 V __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float to_float(_Float16 v) { return (float)v; }
+    static __device__ __forceinline__ _Float16 from_float(float v) { return (_Float16)v; }
+    static __device__ __forceinline__ float4 unpack(V v) { return make_float4((float)v.x, (float)v.y, (float)v.z, (float)v.w); }
+    static __device__ __forceinline__ V pack(float4 f) {
+        V v; v.x = (_Float16)f.x; v.y = (_Float16)f.y; v.z = (_Float16)f.z; v.w = (_Float16)f.w; return v;
+    }
+};
+template <> struct Elem<bf16_t> {
+    typedef unsigned short V __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ float up(unsigned short h) { return u2f((uint32_t)h << 16); }
+    static __device__ __forceinline__ unsigned short down(float f) {
+        const uint32_t u = f2u(f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40u);      // NaN stays NaN
+        return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    static __device__ __forceinline__ float to_float(bf16_t v) { return up(v.bits); }
+    static __device__ __forceinline__ bf16_t from_float(float v) { bf16_t r; r.bits = down(v); return r; }
+    static __device__ __forceinline__ float4 unpack(V v) { return make_float4(up(v.x), up(v.y), up(v.z), up(v.w)); }
+    static __device__ __forceinline__ V pack(float4 f) { V v; v.x = down(f.x); v.y = down(f.y); v.z = down(f.z); v.w = down(f.w); return v; }
+};
+template <typename T> constexpr uintptr_t vec_mask() { return 4 * sizeof(T) - 1; }   // alignment of a group of four
+
 struct FocalTerms {
     float loss;                         // alpha_t * (1 - p_t)^gamma * ce
     float dldx;                         // its derivative with respect to the logit
@@ -65,7 +101,7 @@ __device__ __forceinline__ FocalTerms focal_terms(float x, bool t, float alpha, 
 }
 
 struct LossArgs {
-    const float* logits;                // [batch, n, C], image stride batch_stride (elements)
+    const void* logits;                 // [batch, n, C] of the element type, image stride batch_stride (elements)
     long long batch_stride;
     long long n;
     int num_classes;
@@ -105,18 +141,19 @@ struct ThreadGroups {
     long long m[LPT / 4];               // matched index of that anchor
 };
 
-__device__ __forceinline__ void load_groups(const LossArgs& p, int b, const float* src, long long e0, long long E,
+template <typename T>
+__device__ __forceinline__ void load_groups(const LossArgs& p, int b, const T* src, long long e0, long long E,
                                             bool vec_ok, bool small, ThreadGroups& g) {
     const int tid = threadIdx.x;
 #pragma unroll
     for (int it = 0; it < LPT / 4; ++it) {
         const long long eb = e0 + it * (LT * 4) + tid * 4;
         if (vec_ok) {
-            const float4 v = *reinterpret_cast<const float4*>(src + eb);
+            const float4 v = Elem<T>::unpack(*reinterpret_cast<const typename Elem<T>::V*>(src + eb));
             g.x[it][0] = v.x; g.x[it][1] = v.y; g.x[it][2] = v.z; g.x[it][3] = v.w;
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) g.x[it][k] = (eb + k < E) ? src[eb + k] : 0.0f;
+            for (int k = 0; k < 4; ++k) g.x[it][k] = (eb + k < E) ? Elem<T>::to_float(src[eb + k]) : 0.0f;
         }
         split_index(eb < E ? eb : 0, p.num_classes, small, g.a[it], g.c[it]);
         g.m[it] = (eb < E) ? p.matched[(long long)b * p.n + g.a[it]] : -2;
@@ -127,8 +164,8 @@ __device__ __forceinline__ void load_groups(const LossArgs& p, int b, const floa
 // four classes: a group of four elements then spans at most two anchors, so two matched indices cover it, nothing
 // needs a bounds test and the element loop is free of branches.  f(it, k, x, is_target, valid) is called for every
 // element (valid = its anchor is not ignored); returns the thread's number of foreground anchors.
-template <typename F>
-__device__ __forceinline__ int for_each_element_fast(const LossArgs& p, int b, const float* src, long long e0, bool small,
+template <typename T, typename F>
+__device__ __forceinline__ int for_each_element_fast(const LossArgs& p, int b, const T* src, long long e0, bool small,
                                                      F f) {
     const int tid = threadIdx.x;
     const int C = p.num_classes;
@@ -141,12 +178,10 @@ __device__ __forceinline__ int for_each_element_fast(const LossArgs& p, int b, c
     for (int it = 0; it < LPT / 4; ++it) {
         const long long eb = e0 + it * (LT * 4) + tid * 4;
         // streamed once: non-temporal loads keep these lines from displacing others in the caches
-        const vec4f xv = __builtin_nontemporal_load(reinterpret_cast<const vec4f*>(src + eb));
-        x[it] = make_float4(xv.x, xv.y, xv.z, xv.w);
+        x[it] = Elem<T>::unpack(__builtin_nontemporal_load(reinterpret_cast<const typename Elem<T>::V*>(src + eb)));
         long long a;
         split_index(eb, C, small, a, c0[it]);
         m0[it] = __builtin_nontemporal_load(mrow + a);
-
         m1[it] = straddle ? mrow[a + 1 < p.n ? a + 1 : a] : 0;
     }
     int cls0[LPT / 4], cls1[LPT / 4];
@@ -202,7 +237,7 @@ __device__ __forceinline__ int for_each_element(const LossArgs& p, int b, long l
     return fg;
 }
 
-template <bool G2>
+template <bool G2, typename T>
 __global__ __launch_bounds__(LT) void focal_forward_kernel(LossArgs p, double* __restrict__ part_loss,
                                                            int* __restrict__ part_fg) {
     __shared__ float s_sum[LT / 64];
@@ -212,8 +247,8 @@ __global__ __launch_bounds__(LT) void focal_forward_kernel(LossArgs p, double* _
     const long long E = p.n * p.num_classes;
     const bool small = E <= 0xffffffffll;
     const long long e0 = (long long)blockIdx.x * LCHUNK;
-    const float* src = p.logits + (long long)b * p.batch_stride;
-    const bool vec_ok = ((((uintptr_t)(src + e0)) & 15) == 0) && (e0 + LCHUNK <= E);
+    const T* src = (const T*)p.logits + (long long)b * p.batch_stride;
+    const bool vec_ok = ((((uintptr_t)(src + e0)) & vec_mask<T>()) == 0) && (e0 + LCHUNK <= E);
     float acc = 0.0f;
     int fg;
     if (vec_ok && p.num_classes >= 4) {
@@ -281,19 +316,19 @@ __global__ __launch_bounds__(1024) void focal_finalize_kernel(const double* __re
     if (tid == 0) *loss_out = (float)(s_total / (double)batch);
 }
 
-template <bool G2>
+template <bool G2, typename T>
 __global__ __launch_bounds__(LT) void focal_backward_kernel(LossArgs p, const int* __restrict__ num_fg,
                                                             const float* __restrict__ grad_out, int batch,
-                                                            float* __restrict__ grad_logits) {
+                                                            T* __restrict__ grad_logits) {
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const long long E = p.n * p.num_classes;
     const bool small = E <= 0xffffffffll;
     const long long e0 = (long long)blockIdx.x * LCHUNK;
-    const float* src = p.logits + (long long)b * p.batch_stride;
-    float* dst = grad_logits + (long long)b * E;                     // the gradient is written contiguously
-    const bool vec_ok = ((((uintptr_t)(src + e0)) & 15) == 0) && ((((uintptr_t)(dst + e0)) & 15) == 0) &&
-                        (e0 + LCHUNK <= E);
+    const T* src = (const T*)p.logits + (long long)b * p.batch_stride;
+    T* dst = grad_logits + (long long)b * E;                         // the gradient is written contiguously
+    const bool vec_ok = ((((uintptr_t)(src + e0)) & vec_mask<T>()) == 0) &&
+                        ((((uintptr_t)(dst + e0)) & vec_mask<T>()) == 0) && (e0 + LCHUNK <= E);
     const int nf = num_fg[b];
     const float scale = *grad_out / ((float)(nf > 1 ? nf : 1) * (float)batch);
     float gr[LPT / 4][4];
@@ -317,11 +352,12 @@ __global__ __launch_bounds__(LT) void focal_backward_kernel(LossArgs p, const in
     for (int it = 0; it < LPT / 4; ++it) {
         const long long eb = e0 + it * (LT * 4) + tid * 4;
         if (vec_ok) {
-            *reinterpret_cast<float4*>(dst + eb) = make_float4(gr[it][0], gr[it][1], gr[it][2], gr[it][3]);
+            *reinterpret_cast<typename Elem<T>::V*>(dst + eb) =
+                Elem<T>::pack(make_float4(gr[it][0], gr[it][1], gr[it][2], gr[it][3]));
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (eb + k < E) dst[eb + k] = gr[it][k];
+                if (eb + k < E) dst[eb + k] = Elem<T>::from_float(gr[it][k]);
         }
     }
 }
@@ -337,12 +373,16 @@ bool loss_layout(int64_t n, int32_t num_classes, int32_t batch, int* blocks, siz
     return true;
 }
 
-int fill_args(LossArgs* a, const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+size_t elem_size(int32_t dtype) {        // 0 for an unknown element type
+    return dtype == OD_DTYPE_F32 ? 4 : (dtype == OD_DTYPE_F16 || dtype == OD_DTYPE_BF16) ? 2 : 0;
+}
+
+int fill_args(LossArgs* a, const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
               const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, float alpha, float gamma,
               int blocks) {
-    if (!cls_logits || !matched || !gt_offsets) return OD_ERR_ARG;
+    if (!cls_logits || !matched || !gt_offsets || elem_size(dtype) == 0) return OD_ERR_ARG;
     if (batch_stride < n * (long long)num_classes) return OD_ERR_ARG;
-    if (((uintptr_t)cls_logits & 3) || ((uintptr_t)matched & 7)) return OD_ERR_ARG;
+    if (((uintptr_t)cls_logits & (elem_size(dtype) - 1)) || ((uintptr_t)matched & 7)) return OD_ERR_ARG;
     a->logits = cls_logits;
     a->batch_stride = batch_stride;
     a->n = n;
@@ -371,7 +411,7 @@ constexpr int RPT = 8;                  // anchors per thread
 constexpr int RCHUNK = RT * RPT;
 
 struct BoxLossArgs {
-    const float* reg;                   // [batch, n, 4]
+    const void* reg;                    // [batch, n, 4] of the element type
     long long reg_stride;               // elements between images
     const float* anchors;               // [n, 4]; images anchor_stride elements apart (0: shared by all images)
     long long anchor_stride;
@@ -470,16 +510,19 @@ __device__ __forceinline__ BoxTerms l1_terms(const BoxLossArgs& p, float4 r, flo
 }
 
 // Terms of anchor `a` of image b if it is foreground; returns false (and touches nothing) otherwise.
+template <typename T>
 __device__ __forceinline__ bool box_terms_of(const BoxLossArgs& p, int b, long long a, long long m, BoxTerms& t) {
     const int m0 = p.gt_offsets[b];
     if (m < 0 || m >= (long long)(p.gt_offsets[b + 1] - m0)) return false;
-    const float4 r = *reinterpret_cast<const float4*>(p.reg + (long long)b * p.reg_stride + a * 4);
+    const float4 r = Elem<T>::unpack(
+        *reinterpret_cast<const typename Elem<T>::V*>((const T*)p.reg + (long long)b * p.reg_stride + a * 4));
     const float4 an = *reinterpret_cast<const float4*>(p.anchors + (long long)b * p.anchor_stride + a * 4);
     const float4 g = *reinterpret_cast<const float4*>(p.gt_boxes + (long long)(m0 + m) * 4);
     t = (p.loss_type == OD_BOX_LOSS_GIOU) ? giou_terms(p, r, an, g) : l1_terms(p, r, an, g);
     return true;
 }
 
+template <typename T>
 __global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, double* __restrict__ part_loss,
                                                               int* __restrict__ part_fg) {
     __shared__ float s_sum[RT / 64];
@@ -499,7 +542,7 @@ __global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, dou
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
         BoxTerms t;
-        if (box_terms_of(p, b, a0 + it * RT + tid, m[it], t)) {
+        if (box_terms_of<T>(p, b, a0 + it * RT + tid, m[it], t)) {
             acc += t.loss;
             ++fg;
         }
@@ -520,14 +563,15 @@ __global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, dou
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(RT) void box_loss_backward_kernel(BoxLossArgs p, const int* __restrict__ num_fg,
                                                                const float* __restrict__ grad_out, int batch,
-                                                               float* __restrict__ grad_reg) {
+                                                               T* __restrict__ grad_reg) {
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const long long a0 = (long long)blockIdx.x * RCHUNK;
     const long long* mrow = p.matched + (long long)b * p.n;
-    float* dst = grad_reg + (long long)b * p.n * 4;                  // the gradient is written contiguously
+    T* dst = grad_reg + (long long)b * p.n * 4;                      // the gradient is written contiguously
     long long m[RPT];
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
@@ -541,9 +585,9 @@ __global__ __launch_bounds__(RT) void box_loss_backward_kernel(BoxLossArgs p, co
         const long long a = a0 + it * RT + tid;
         float4 gr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         BoxTerms t;
-        if (box_terms_of(p, b, a, m[it], t))
+        if (box_terms_of<T>(p, b, a, m[it], t))
             gr = make_float4(scale * t.grad.x, scale * t.grad.y, scale * t.grad.z, scale * t.grad.w);
-        if (a < p.n) *reinterpret_cast<float4*>(dst + a * 4) = gr;
+        if (a < p.n) *reinterpret_cast<typename Elem<T>::V*>(dst + a * 4) = Elem<T>::pack(gr);
     }
 }
 
@@ -557,13 +601,14 @@ bool box_loss_layout(int64_t n, int32_t batch, int* blocks, size_t* part_bytes, 
     return true;
 }
 
-int fill_box_args(BoxLossArgs* a, const float* reg, int64_t reg_stride, const float* anchors, int64_t anchor_stride,
+int fill_box_args(BoxLossArgs* a, const void* reg, int32_t dtype, int64_t reg_stride, const float* anchors,
+                  int64_t anchor_stride,
                   int64_t n, const int64_t* matched, const float* gt_boxes, const int32_t* gt_offsets, int32_t loss_type,
                   float beta, const float* weights, float clip, float eps, int blocks) {
-    if (!reg || !anchors || !matched || !gt_offsets || !weights) return OD_ERR_ARG;
+    if (!reg || !anchors || !matched || !gt_offsets || !weights || elem_size(dtype) == 0) return OD_ERR_ARG;
     if (reg_stride < n * 4 || (anchor_stride != 0 && anchor_stride < n * 4)) return OD_ERR_ARG;
-    // rows are read as 16-byte vectors
-    if (((uintptr_t)reg & 15) || (reg_stride & 3) || ((uintptr_t)anchors & 15) || (anchor_stride & 3) ||
+    // rows are read as vectors of four
+    if (((uintptr_t)reg & (4 * elem_size(dtype) - 1)) || (reg_stride & 3) || ((uintptr_t)anchors & 15) || (anchor_stride & 3) ||
         ((uintptr_t)gt_boxes & 15) || ((uintptr_t)matched & 7))
         return OD_ERR_ARG;
     if (loss_type != OD_BOX_LOSS_L1 && loss_type != OD_BOX_LOSS_SMOOTH_L1 && loss_type != OD_BOX_LOSS_GIOU)
@@ -597,7 +642,7 @@ extern "C" size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, 
     return total > 0 ? total : 256;
 }
 
-extern "C" int od_focal_loss_forward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
+extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                                      const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets,
                                      int32_t batch, float alpha, float gamma, float* loss, float* per_image_loss,
                                      int32_t* num_foreground, void* workspace, size_t workspace_bytes, void* stream) {
@@ -608,22 +653,26 @@ extern "C" int od_focal_loss_forward(const float* cls_logits, int64_t batch_stri
     if (!loss || !per_image_loss || !num_foreground || !workspace) return OD_ERR_ARG;
     if (workspace_bytes < total || ((uintptr_t)workspace & 255)) return OD_ERR_WORKSPACE;
     LossArgs a;
-    const int rc = fill_args(&a, cls_logits, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha, gamma,
-                             blocks);
+    const int rc = fill_args(&a, cls_logits, dtype, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha,
+                             gamma, blocks);
     if (rc != OD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     double* part_loss = (double*)workspace;
     int* part_fg = (int*)((char*)workspace + part);
     if (blocks > 0) {
+        const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_FOCAL_FWD(G2, T) \
+    OD_LAUNCH(OD_KERNEL_FOCAL_FWD, s, hipLaunchKernelGGL((focal_forward_kernel<G2, T>), grid, dim3(LT), 0, s, a, part_loss, part_fg))
         if (gamma == 2.0f) {
-            OD_LAUNCH(OD_KERNEL_FOCAL_FWD, s,
-                      hipLaunchKernelGGL(focal_forward_kernel<true>, dim3((unsigned)blocks, (unsigned)batch), dim3(LT), 0,
-                                         s, a, part_loss, part_fg));
+            if (dtype == OD_DTYPE_F32) { OD_FOCAL_FWD(true, float); }
+            else if (dtype == OD_DTYPE_F16) { OD_FOCAL_FWD(true, _Float16); }
+            else { OD_FOCAL_FWD(true, bf16_t); }
         } else {
-            OD_LAUNCH(OD_KERNEL_FOCAL_FWD, s,
-                      hipLaunchKernelGGL(focal_forward_kernel<false>, dim3((unsigned)blocks, (unsigned)batch), dim3(LT), 0,
-                                         s, a, part_loss, part_fg));
+            if (dtype == OD_DTYPE_F32) { OD_FOCAL_FWD(false, float); }
+            else if (dtype == OD_DTYPE_F16) { OD_FOCAL_FWD(false, _Float16); }
+            else { OD_FOCAL_FWD(false, bf16_t); }
         }
+#undef OD_FOCAL_FWD
     }
     hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
                        blocks, (int)batch, loss, per_image_loss, num_foreground);
@@ -631,30 +680,38 @@ extern "C" int od_focal_loss_forward(const float* cls_logits, int64_t batch_stri
     return OD_OK;
 }
 
-extern "C" int od_focal_loss_backward(const float* cls_logits, int64_t batch_stride, int64_t n, int32_t num_classes,
-                                      const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets,
-                                      int32_t batch, float alpha, float gamma, const int32_t* num_foreground,
-                                      const float* grad_loss, float* grad_logits, void* stream) {
+extern "C" int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n,
+                                      int32_t num_classes, const int64_t* matched, const int64_t* gt_labels,
+                                      const int32_t* gt_offsets, int32_t batch, float alpha, float gamma,
+                                      const int32_t* num_foreground, const float* grad_loss, void* grad_logits,
+                                      void* stream) {
     int blocks;
     size_t part, total;
     if (!loss_layout(n, num_classes, batch, &blocks, &part, &total)) return OD_ERR_ARG;
     if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
-    if (!num_foreground || !grad_loss || !grad_logits || ((uintptr_t)grad_logits & 3)) return OD_ERR_ARG;
+    if (!num_foreground || !grad_loss || !grad_logits || elem_size(dtype) == 0) return OD_ERR_ARG;
+    if ((uintptr_t)grad_logits & (elem_size(dtype) - 1)) return OD_ERR_ARG;
     LossArgs a;
-    const int rc = fill_args(&a, cls_logits, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha, gamma,
-                             blocks);
+    const int rc = fill_args(&a, cls_logits, dtype, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha,
+                             gamma, blocks);
     if (rc != OD_OK) return rc;
     if (blocks == 0) return OD_OK;
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_FOCAL_BWD(G2, T)                                                                                       \
+    OD_LAUNCH(OD_KERNEL_FOCAL_BWD, s,                                                                             \
+              hipLaunchKernelGGL((focal_backward_kernel<G2, T>), grid, dim3(LT), 0, s, a, num_foreground, grad_loss, \
+                                 (int)batch, (T*)grad_logits))
     if (gamma == 2.0f) {
-        OD_LAUNCH(OD_KERNEL_FOCAL_BWD, s,
-                  hipLaunchKernelGGL(focal_backward_kernel<true>, dim3((unsigned)blocks, (unsigned)batch), dim3(LT), 0, s,
-                                     a, num_foreground, grad_loss, (int)batch, grad_logits));
+        if (dtype == OD_DTYPE_F32) { OD_FOCAL_BWD(true, float); }
+        else if (dtype == OD_DTYPE_F16) { OD_FOCAL_BWD(true, _Float16); }
+        else { OD_FOCAL_BWD(true, bf16_t); }
     } else {
-        OD_LAUNCH(OD_KERNEL_FOCAL_BWD, s,
-                  hipLaunchKernelGGL(focal_backward_kernel<false>, dim3((unsigned)blocks, (unsigned)batch), dim3(LT), 0, s,
-                                     a, num_foreground, grad_loss, (int)batch, grad_logits));
+        if (dtype == OD_DTYPE_F32) { OD_FOCAL_BWD(false, float); }
+        else if (dtype == OD_DTYPE_F16) { OD_FOCAL_BWD(false, _Float16); }
+        else { OD_FOCAL_BWD(false, bf16_t); }
     }
+#undef OD_FOCAL_BWD
     return OD_OK;
 }
 
@@ -665,7 +722,7 @@ extern "C" size_t od_box_loss_workspace_bytes(int64_t n, int32_t batch) {
     return total > 0 ? total : 256;
 }
 
-extern "C" int od_box_loss_forward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+extern "C" int od_box_loss_forward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
                                    int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
                                    const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta,
                                    const float* weights, float bbox_xform_clip, float eps, float* loss,
@@ -678,16 +735,20 @@ extern "C" int od_box_loss_forward(const float* bbox_regression, int64_t batch_s
     if (!loss || !per_image_loss || !num_foreground || !workspace) return OD_ERR_ARG;
     if (workspace_bytes < total || ((uintptr_t)workspace & 255)) return OD_ERR_WORKSPACE;
     BoxLossArgs a;
-    const int rc = fill_box_args(&a, bbox_regression, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
+    const int rc = fill_box_args(&a, bbox_regression, dtype, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
                                  gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
     if (rc != OD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     double* part_loss = (double*)workspace;
     int* part_fg = (int*)((char*)workspace + part);
     if (blocks > 0) {
-        OD_LAUNCH(OD_KERNEL_BOX_LOSS_FWD, s,
-                  hipLaunchKernelGGL(box_loss_forward_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(RT), 0, s, a,
-                                     part_loss, part_fg));
+        const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_BOX_FWD(T) \
+    OD_LAUNCH(OD_KERNEL_BOX_LOSS_FWD, s, hipLaunchKernelGGL((box_loss_forward_kernel<T>), grid, dim3(RT), 0, s, a, part_loss, part_fg))
+        if (dtype == OD_DTYPE_F32) { OD_BOX_FWD(float); }
+        else if (dtype == OD_DTYPE_F16) { OD_BOX_FWD(_Float16); }
+        else { OD_BOX_FWD(bf16_t); }
+#undef OD_BOX_FWD
     }
     hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
                        blocks, (int)batch, loss, per_image_loss, num_foreground);
@@ -695,25 +756,32 @@ extern "C" int od_box_loss_forward(const float* bbox_regression, int64_t batch_s
     return OD_OK;
 }
 
-extern "C" int od_box_loss_backward(const float* bbox_regression, int64_t batch_stride, const float* anchors,
+extern "C" int od_box_loss_backward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
                                     int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
                                     const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta,
                                     const float* weights, float bbox_xform_clip, float eps,
-                                    const int32_t* num_foreground, const float* grad_loss, float* grad_regression,
+                                    const int32_t* num_foreground, const float* grad_loss, void* grad_regression,
                                     void* stream) {
     int blocks;
     size_t part, total;
     if (!box_loss_layout(n, batch, &blocks, &part, &total)) return OD_ERR_ARG;
     if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
-    if (!num_foreground || !grad_loss || !grad_regression || ((uintptr_t)grad_regression & 15)) return OD_ERR_ARG;
+    if (!num_foreground || !grad_loss || !grad_regression || elem_size(dtype) == 0) return OD_ERR_ARG;
+    if ((uintptr_t)grad_regression & (4 * elem_size(dtype) - 1)) return OD_ERR_ARG;
     BoxLossArgs a;
-    const int rc = fill_box_args(&a, bbox_regression, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
+    const int rc = fill_box_args(&a, bbox_regression, dtype, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
                                  gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
     if (rc != OD_OK) return rc;
     if (blocks == 0) return OD_OK;
     hipStream_t s = (hipStream_t)stream;
-    OD_LAUNCH(OD_KERNEL_BOX_LOSS_BWD, s,
-              hipLaunchKernelGGL(box_loss_backward_kernel, dim3((unsigned)blocks, (unsigned)batch), dim3(RT), 0, s, a,
-                                 num_foreground, grad_loss, (int)batch, grad_regression));
+    const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_BOX_BWD(T)                                                                                                \
+    OD_LAUNCH(OD_KERNEL_BOX_LOSS_BWD, s,                                                                             \
+              hipLaunchKernelGGL((box_loss_backward_kernel<T>), grid, dim3(RT), 0, s, a, num_foreground, grad_loss, \
+                                 (int)batch, (T*)grad_regression))
+    if (dtype == OD_DTYPE_F32) { OD_BOX_BWD(float); }
+    else if (dtype == OD_DTYPE_F16) { OD_BOX_BWD(_Float16); }
+    else { OD_BOX_BWD(bf16_t); }
+#undef OD_BOX_BWD
     return OD_OK;
 }

@@ -171,6 +171,9 @@ def _box_loss(type: str, box_coder: BoxCoder, anchors_per_image: Tensor, matched
     return generalized_box_iou_loss(pred, matched_gt_boxes_per_image, reduction="sum", eps=eps)
 
 
+_FUSED_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
+
+
 class _RetinaNetFocalLoss(torch.autograd.Function):
     """Classification-head loss of a whole batch in one streamed pass each way (kernels.focal_loss_*)."""
 
@@ -204,8 +207,9 @@ def _matched_rows(matched_idxs: List[Tensor], n: int) -> Tensor:
 def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor], labels: List[Tensor],
                                   alpha: float = 0.25, gamma: float = 2.0) -> Optional[Tensor]:
     """Fused path of RetinaNetClassificationHead.compute_loss; None if the inputs do not qualify (not on the GPU,
-    not fp32, or logits whose inner dimensions are not contiguous) and the caller should use the torch ops."""
-    if not (cls_logits.is_cuda and cls_logits.dtype is torch.float32 and cls_logits.dim() == 3):
+    not fp32 / fp16 / bf16, or logits whose inner dimensions are not contiguous) and the caller should use the torch
+    ops.  16-bit logits (a head running under autocast) are read as they are and the loss is evaluated in fp32."""
+    if not (cls_logits.is_cuda and cls_logits.dtype in _FUSED_DTYPES and cls_logits.dim() == 3):
         return None
     if cls_logits.stride(2) != 1 or cls_logits.stride(1) != cls_logits.shape[2]:
         return None
@@ -248,23 +252,25 @@ _BOX_LOSS_TYPES = {"l1": _C.BOX_LOSS_L1, "smooth_l1": _C.BOX_LOSS_SMOOTH_L1, "gi
 def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: Tensor, anchors: List[Tensor],
                               matched_idxs: List[Tensor], gt_boxes: List[Tensor], cnf=None) -> Optional[Tensor]:
     """Fused path of RetinaNetRegressionHead.compute_loss; None if the inputs do not qualify (not on the GPU, not
-    fp32, rows not contiguous, anchors or targets that need a gradient) and the caller should use the torch ops."""
+    fp32 / fp16 / bf16, rows not contiguous, anchors or targets that need a gradient) and the caller should use the torch
+    ops.  Under autocast the regression and the anchors arrive in a 16-bit type: the values are used as they are and
+    the loss is evaluated in fp32."""
     torch._assert(type in _BOX_LOSS_TYPES, f"Unsupported loss: {type}")
-    if not (bbox_regression.is_cuda and bbox_regression.dtype is torch.float32 and bbox_regression.dim() == 3):
+    if not (bbox_regression.is_cuda and bbox_regression.dtype in _FUSED_DTYPES and bbox_regression.dim() == 3):
         return None
     B, n = bbox_regression.shape[0], bbox_regression.shape[1]
     if (bbox_regression.shape[2] != 4 or bbox_regression.stride(2) != 1 or bbox_regression.stride(1) != 4
-            or bbox_regression.stride(0) % 4 or bbox_regression.data_ptr() % 16):
+            or bbox_regression.stride(0) % 4 or bbox_regression.data_ptr() % (4 * bbox_regression.element_size())):
         return None
-    if any(a.requires_grad or a.dtype is not torch.float32 or a.shape != (n, 4) for a in anchors):
+    if any(a.requires_grad or a.dtype not in _FUSED_DTYPES or a.shape != (n, 4) for a in anchors):
         return None
     if any(g.requires_grad for g in gt_boxes):
         return None
     first = anchors[0]
     if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
-        anchor_table = first.contiguous()                    # AnchorGenerator hands every image the same tensor
+        anchor_table = first.float().contiguous()            # AnchorGenerator hands every image the same tensor
     else:
-        anchor_table = torch.stack([a.contiguous() for a in anchors])
+        anchor_table = torch.stack([a.float() for a in anchors])
     matched = _matched_rows(matched_idxs, n)
     offsets = [0]
     for g in gt_boxes:
@@ -275,6 +281,6 @@ def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: T
         boxes = torch.zeros((1, 4), dtype=torch.float32, device=bbox_regression.device)
     gt_offsets = kernels._device_ints(offsets, bbox_regression.device)
     beta = float(cnf["beta"]) if cnf is not None and "beta" in cnf else 1.0
-    eps = float(torch.finfo(bbox_regression.dtype).eps)
+    eps = float(torch.finfo(bbox_regression.dtype).eps)  # as _box_loss: the epsilon of the regression's element type
     return _RetinaNetBoxLoss.apply(bbox_regression, anchor_table, matched, boxes, gt_offsets, _BOX_LOSS_TYPES[type], beta,
                                    tuple(float(w) for w in box_coder.weights), float(box_coder.bbox_xform_clip), eps)

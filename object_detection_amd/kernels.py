@@ -373,9 +373,19 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
 
 
 # ------------------------------------------------------------------------------------------------
+_DTYPE_CODES = {torch.float32: _C.DTYPE_F32, torch.float16: _C.DTYPE_F16, torch.bfloat16: _C.DTYPE_BF16}
+
+
+def _dtype_code(t: Tensor, what: str) -> int:
+    code = _DTYPE_CODES.get(t.dtype)
+    if code is None:
+        raise TypeError(f"{what}: element type {t.dtype} is not supported (float32, float16, bfloat16)")
+    return code
+
+
 def focal_loss_forward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
                        gamma: float) -> Tuple[Tensor, Tensor, Tensor]:
-    """RetinaNet classification loss for a batch.  cls_logits [B,N,C] fp32 (inner dims contiguous), matched int64
+    """RetinaNet classification loss for a batch.  cls_logits [B,N,C] fp32 / fp16 / bf16 (inner dims contiguous), matched int64
     [B,N], gt_labels int64 [sum M], gt_offsets int32 [B+1].  Returns (loss [1], per_image [B], num_fg int32 [B])."""
     _require_gpu(cls_logits, "cls_logits")
     dev = cls_logits.device
@@ -385,7 +395,8 @@ def focal_loss_forward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, g
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     per_image = torch.empty((B,), dtype=torch.float32, device=dev)
     num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
-    rc = lib.od_focal_loss_forward(_ptr(cls_logits), cls_logits.stride(0), n, C, _ptr(matched), _ptr(gt_labels),
+    rc = lib.od_focal_loss_forward(_ptr(cls_logits), _dtype_code(cls_logits, "cls_logits"), cls_logits.stride(0), n, C,
+                                   _ptr(matched), _ptr(gt_labels),
                                    _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(loss), _ptr(per_image),
                                    _ptr(num_fg), _ptr(ws), ws.numel(), _stream(dev))
     _C.check(rc, "od_focal_loss_forward")
@@ -396,8 +407,9 @@ def focal_loss_backward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, 
                         gamma: float, num_fg: Tensor, grad_loss: Tensor) -> Tensor:
     dev = cls_logits.device
     B, n, C = cls_logits.shape
-    grad = torch.empty((B, n, C), dtype=torch.float32, device=dev)
-    rc = _C.lib().od_focal_loss_backward(_ptr(cls_logits), cls_logits.stride(0), n, C, _ptr(matched), _ptr(gt_labels),
+    grad = torch.empty((B, n, C), dtype=cls_logits.dtype, device=dev)
+    rc = _C.lib().od_focal_loss_backward(_ptr(cls_logits), _dtype_code(cls_logits, "cls_logits"), cls_logits.stride(0), n, C,
+                                         _ptr(matched), _ptr(gt_labels),
                                          _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(num_fg),
                                          _ptr(grad_loss), _ptr(grad), _stream(dev))
     _C.check(rc, "od_focal_loss_backward")
@@ -409,7 +421,8 @@ def _box_loss_call_args(bbox_regression: Tensor, anchors: Tensor, matched: Tenso
     B, n, _ = bbox_regression.shape
     anchor_stride = 0 if anchors.dim() == 2 else anchors.stride(0)
     w = (ctypes.c_float * 4)(*[float(x) for x in weights])
-    return (_ptr(bbox_regression), bbox_regression.stride(0), _ptr(anchors), anchor_stride, n, _ptr(matched),
+    return (_ptr(bbox_regression), _dtype_code(bbox_regression, "bbox_regression"), bbox_regression.stride(0),
+            _ptr(anchors), anchor_stride, n, _ptr(matched),
             _ptr(gt_boxes), _ptr(gt_offsets), B, int(loss_type), float(beta), w, float(clip), float(eps))
 
 
@@ -438,7 +451,7 @@ def box_loss_backward(bbox_regression: Tensor, anchors: Tensor, matched: Tensor,
                       grad_loss: Tensor) -> Tensor:
     dev = bbox_regression.device
     B, n, _ = bbox_regression.shape
-    grad = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    grad = torch.empty((B, n, 4), dtype=bbox_regression.dtype, device=dev)
     args = _box_loss_call_args(bbox_regression, anchors, matched, gt_boxes, gt_offsets, loss_type, beta, weights, clip, eps)
     rc = _C.lib().od_box_loss_backward(*args, _ptr(num_fg), _ptr(grad_loss), _ptr(grad), _stream(dev))
     _C.check(rc, "od_box_loss_backward")

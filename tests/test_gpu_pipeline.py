@@ -190,6 +190,30 @@ def test_eval_forward_reads_head_maps_in_place(device, arch):
             assert torch.equal(d[k], r[k]), k
 
 
+def test_training_step_under_autocast(device):
+    """The reference trains under torch.cuda.amp.autocast (use_amp): the heads emit fp16, anchors are cast to fp16 and
+    the loss dictionary is fp32.  The step runs through the fused kernels and stays close to the fp32 step (the
+    16-bit rounding of the head outputs and anchors is the only difference)."""
+    torch.manual_seed(0)
+    model = get_model(4, backbone="pyramid_stub", layers=[0], out_channels=32, min_size=128, max_size=128).to(device)
+    images = [torch.rand(3, 128, 128, device=device), torch.rand(3, 100, 120, device=device)]
+    targets = [{"boxes": torch.tensor([[10., 10., 60., 70.], [30., 40., 90., 100.]], device=device),
+                "labels": torch.tensor([1, 2], device=device)},
+               {"boxes": torch.tensor([[5., 8., 50., 40.]], device=device), "labels": torch.tensor([3], device=device)}]
+    model.train()
+    full = model(images, targets)
+    with torch.autocast("cuda", dtype=torch.float16):
+        amp = model(images, targets)
+        total = sum(amp.values())
+    for k in full:
+        assert amp[k].dtype is torch.float32 and type(amp[k].grad_fn).__name__.startswith("_RetinaNet"), k
+        assert abs(amp[k].item() - full[k].item()) <= 2e-2 * abs(full[k].item()) + 1e-4, (k, amp[k].item(), full[k].item())
+    scaler = torch.amp.GradScaler("cuda")
+    scaler.scale(total).backward()
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 0 and all(bool(torch.isfinite(g).all()) for g in grads)
+
+
 def test_compute_loss_matches_checker(device):
     cfg = dataclasses.replace(synthetic.CFG1, num_gt=30)
     model = _model(cfg, device)
@@ -369,3 +393,42 @@ def _targets_of(logits, matched, labels):
     fg = matched >= 0
     t[fg, labels[matched[fg]]] = 1.0
     return t
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fused_losses_take_autocast_head_outputs(device, dtype):
+    """Head outputs in the 16-bit types autocast training produces go through the fused kernels as they are: the loss
+    equals the fp32 evaluation of the torch restatement on the same (already rounded) values within 1e-5, and the
+    gradients, returned in the 16-bit type, equal its gradients within one rounding of that type."""
+    cfg = dataclasses.replace(synthetic.CFG1, num_gt=40, cfg_id=79)
+    model = _model(cfg, device)
+    anchors_dev = torch.cat(_anchors(model, cfg, device))
+    anchors_half = anchors_dev.to(dtype)                      # AnchorGenerator casts to the feature dtype
+    anchors = anchors_half.float().cpu()
+    head = synthetic.make_head_outputs(cfg)
+    cls16, reg16 = head["cls_logits"].to(dtype), head["bbox_regression"].to(dtype)
+    targets = synthetic.make_targets(cfg, empty_image=1)
+    matched = tv.retinanet_match([t["boxes"] for t in targets], [anchors] * cfg.batch, cfg.fg_iou_thresh, cfg.bg_iou_thresh)
+    cls_ref = cls16.float().requires_grad_(True)
+    reg_ref = reg16.float().requires_grad_(True)
+    eps = float(torch.finfo(dtype).eps)
+    ref_c = tv.retinanet_head_loss(targets, {"cls_logits": cls_ref, "bbox_regression": reg_ref.detach()},
+                                   [anchors] * cfg.batch, matched)["classification"]
+    ref_r = tv.retinanet_head_loss_regression(targets, reg_ref, [anchors] * cfg.batch, matched, eps=eps)
+    (ref_c + ref_r).backward()
+    cls_d, reg_d = cls16.to(device).requires_grad_(True), reg16.to(device).requires_grad_(True)
+    t_dev = [{k: v.to(device) for k, v in t.items()} for t in targets]
+    m_dev = list(torch.stack(matched).to(device).unbind(0))
+    losses = model.head.compute_loss(t_dev, {"cls_logits": cls_d, "bbox_regression": reg_d}, [anchors_half] * cfg.batch, m_dev)
+    for k in losses:
+        assert losses[k].dtype is torch.float32 and type(losses[k].grad_fn).__name__.startswith("_RetinaNet"), k
+    assert abs(losses["classification"].item() - ref_c.item()) <= 1e-5 * abs(ref_c.item())
+    assert abs(losses["bbox_regression"].item() - ref_r.item()) <= 1e-5 * abs(ref_r.item())
+    (losses["classification"] + losses["bbox_regression"]).backward()
+    ulp = float(torch.finfo(dtype).eps)
+    for got, want in ((cls_d.grad, cls_ref.grad), (reg_d.grad, reg_ref.grad)):
+        assert got.dtype is dtype
+        g, w = got.float().cpu(), want
+        spacing = 2.0 ** -24 if dtype is torch.float16 else 0.0      # fp16 subnormal spacing (no loss scaling here)
+        tol = 1e-5 * w.abs().max() + ulp * w.abs() + spacing
+        assert bool(((g - w).abs() <= tol).all()), float((g - w).abs().max())
