@@ -277,7 +277,9 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_BOX_LOSS_FWD 14   /* od_box_loss_forward: the streaming kernel                 */
 #define OD_KERNEL_BOX_LOSS_BWD 15
 #define OD_KERNEL_PREPROCESS 16
-#define OD_KERNEL_COUNT 17
+#define OD_KERNEL_SAMPLE 17         /* od_select_candidates: sampled score bound per (image, level)   */
+#define OD_KERNEL_FILTER_REDO 18    /* od_select_candidates: second filter pass (normally exits at once) */
+#define OD_KERNEL_COUNT 19
 int od_profile_select(int32_t kernel_id);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 

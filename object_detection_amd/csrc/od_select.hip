@@ -33,11 +33,25 @@ constexpr int CAP = 8192;          // keys held in LDS by the select kernel
 constexpr int HBITS = 12;
 constexpr int HBINS = 1 << HBITS;  // histogram bins per radix level
 constexpr int CSTRIDE = 64;        // one key counter per 256 bytes: atomics on one cache line serialise
+constexpr long long SAMPLE_MIN = 262144;   // levels with at least this many logits get a sampled score cut
+constexpr int SAMPLE_RUN = 16;     // consecutive logits per sample position (one 64-byte sector)
+
+// Per (image, level): a lower bound on the scores that can be among the best K, estimated from a sample of the level
+// (sample_kernel).  The filter emits only keys with score >= cut; if fewer than K valid keys come out, the estimate
+// was too high and the level is filtered again without the cut (filter_kernel in redo mode), so the result never
+// depends on the sample.
+struct CutInfo {
+    float cut;                     // score bound (only meaningful when active)
+    float pre;                     // logits <= pre cannot reach it
+    int active;
+    int pad;
+};
 
 struct FilterParams {
     int num_levels;
     int num_classes;
     int has_ctr;
+    int topk;
     int total_chunks;                       // per image
     int chunk_start[OD_MAX_LEVELS + 1];     // first chunk id of each level
     long long level_elems[OD_MAX_LEVELS];   // N_l * C
@@ -115,13 +129,17 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
 // threshold); the select kernel ignores zero keys.  The kernel is a stream: everything a wave does after its
 // loads is kept free of further memory round trips, which under load cost as much as the loads themselves.
 __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
-                                                    unsigned int* __restrict__ key_count) {
+                                                    unsigned int* __restrict__ key_count,
+                                                    unsigned int* __restrict__ key_valid,
+                                                    unsigned int* __restrict__ key_count_redo,
+                                                    const CutInfo* __restrict__ cuts, int redo) {
     constexpr int ITERS = CHUNK / (ST * 4);
     constexpr int QCAP = 512;                      // queue entries per wave and pass
     static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
     __shared__ unsigned long long s_queue[ST / 64][QCAP];
     __shared__ int s_tot[ST / 64];
     __shared__ unsigned int s_base;
+    __shared__ unsigned int s_valid;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
@@ -130,6 +148,19 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
 #pragma unroll
     for (int i = 1; i < OD_MAX_LEVELS; ++i)
         if (i < p.num_levels && chunk >= p.chunk_start[i]) l = i;
+    const long long slot = (long long)b * p.num_levels + l;
+    const CutInfo ci = cuts[slot];
+    float pre = p.pre_logit, cut = -__builtin_inff();
+    int prefilter = p.prefilter;
+    if (redo) {
+        // second pass: only levels whose sampled cut left fewer than K valid keys, this time without the cut
+        if (!(ci.active && key_valid[slot * CSTRIDE] < (unsigned int)p.topk)) return;
+    } else if (ci.active) {
+        pre = ci.pre;
+        cut = ci.cut;
+        prefilter = 1;
+    }
+    if (tid == 0) s_valid = 0u;
     const long long E = p.level_elems[l];
     const long long e0 = (long long)(chunk - p.chunk_start[l]) * CHUNK;
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
@@ -157,7 +188,6 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         };
         v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
     }
-    const float pre = p.pre_logit;
     unsigned int pending_all = 0u;                 // bit it*4+k: that element may reach the threshold
     auto mark = [&](const vec4f& v, int it) {
         unsigned int m = 0u;
@@ -165,7 +195,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
         pending_all |= m << (it * 4);
     };
-    if (p.prefilter) {
+    if (prefilter) {
         mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
     } else {
         pending_all = 0xffffffffu;                 // threshold <= 0: every element is scored
@@ -192,7 +222,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     if (wg_total == 0) return;                     // nothing in this chunk can pass
 
     unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
-    unsigned int* counter = key_count + ((long long)b * p.num_levels + l) * CSTRIDE;
+    unsigned int* counter = (redo ? key_count_redo : key_count) + slot * CSTRIDE;
     unsigned long long* queue = s_queue[wave];
     // Usual case: every wave's queue holds all its candidates; the workgroup reserves its slots with ONE
     // atomic, requested before the scoring.  Otherwise each wave makes four passes of 8 element slots
@@ -231,20 +261,28 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int nvalid = 0;                            // valid keys of this wave and pass
         for (int i0 = 0; i0 < total; i0 += 64) {   // every lane scores its own entry and overwrites it with the key
+            bool ok = false;
             if (i0 + lane < total) {
                 const unsigned long long ent = queue[i0 + lane];
                 const uint32_t flat = flat_of(p, l, (uint32_t)e0 + (uint32_t)ent);
                 const float sc = score_of(p, l, b, u2f((uint32_t)(ent >> 32)), flat);
-                queue[i0 + lane] = (sc > p.thresh) ? (((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat)) : 0ull;
+                ok = sc > p.thresh && sc >= cut;
+                queue[i0 + lane] = ok ? (((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat)) : 0ull;
             }
+            nvalid += __popcll(__ballot(ok));
         }
+        // valid keys per (image, level): decides after the kernel whether the sampled cut was low enough
         if (one_pass) {
+            if (lane == 0 && nvalid) atomicAdd(&s_valid, (unsigned int)nvalid);
             if (tid == 0) s_base = wg_base;
             __syncthreads();
             base = s_base + (unsigned int)before_me;
+            if (tid == 0 && !redo && s_valid) atomicAdd(key_valid + slot * CSTRIDE, s_valid);
         } else {
             base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
+            if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
         }
         for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
     }
@@ -284,6 +322,137 @@ __device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb,
         }
     }
     __syncthreads();
+}
+
+// One workgroup per (image, level).  Levels with at least SAMPLE_MIN logits: S logits are read in runs of SAMPLE_RUN
+// at hashed positions (one run per window of E / runs logits) and the r-th best of them, r = 3*K*S/E + 32, is located
+// to 24 bits with two histogram passes.  About 3K + 32*E/S logits of the level are at least as good, so with
+// overwhelming probability at least K are -- and if not, the filter's redo pass repairs it.
+// Without centre-ness the score is a non-decreasing function of the logit (up to the last bits of the specified
+// sigmoid), so the samples are ranked by their logits and only the located bound is put through the sigmoid; with
+// centre-ness every sample is scored.  The bounds handed to the filter carry margins that cover those last bits and
+// the rounding of logf: a bound that is too low only lets more keys through.
+__device__ __forceinline__ uint32_t ordered_bits(float x) {        // monotone map of a float onto unsigned integers
+    const uint32_t u = f2u(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(uint32_t k) { return u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+__global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* __restrict__ cuts) {
+    __shared__ unsigned int s_hist[HBINS];
+    __shared__ int s_tmp[32];
+    const int tid = threadIdx.x;
+    const int l = blockIdx.x, b = blockIdx.y;
+    const long long E = p.level_elems[l];
+    CutInfo out;
+    out.cut = 0.0f; out.pre = p.pre_logit; out.active = 0; out.pad = 0;
+    if (E < SAMPLE_MIN) {
+        if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
+        return;
+    }
+    long long S = (E / 64) & ~16383ll;
+    S = S < 16384 ? 16384 : (S > 262144 ? 262144 : S);
+    const long long runs = S / SAMPLE_RUN;
+    const long long window = E / runs;                         // >= 512 logits
+    const long long r64 = (3ll * p.topk * S + E - 1) / E + 32;
+    if (r64 > S / 4) {                                         // the cut would remove little
+        if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
+        return;
+    }
+    const int r = (int)r64;
+    const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
+    // f(rank key) for every sample that can pass the threshold; the loads of 16 samples are in flight together
+    // (S is a multiple of 16 * SEL_T)
+    const uint32_t window32 = (uint32_t)window, spread = window32 - (SAMPLE_RUN - 1);
+    constexpr int U = 16;
+    auto load_batch = [&](uint32_t base, uint32_t* key) {       // rank keys of 16 samples (0: cannot pass)
+        float x[U];
+        uint32_t pos[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t i = base + u * SEL_T + tid;
+            const uint32_t run = i / SAMPLE_RUN;
+            pos[u] = run * window32 + __umulhi(run * 2654435761u, spread) + (i % SAMPLE_RUN);
+            x[u] = src[pos[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            key[u] = 0u;
+            if (p.prefilter && x[u] <= p.pre_logit) continue;
+            if (p.has_ctr) {
+                const float sc = score_of(p, l, b, x[u], flat_of(p, l, pos[u]));
+                if (sc > p.thresh) key[u] = f2u(sc);
+            } else {
+                key[u] = ordered_bits(x[u]);
+            }
+        }
+    };
+    auto for_each_sample = [&](auto f) {
+        for (uint32_t base = 0; base < (uint32_t)S; base += SEL_T * U) {
+            uint32_t key[U];
+            load_batch(base, key);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (key[u]) f(key[u]);
+        }
+    };
+    // up to 32 samples per thread stay in registers for the second pass; larger samples are read again
+    const bool in_regs = S <= 2 * SEL_T * U;
+    uint32_t kreg[2 * U];
+    // pass A: the top 12 bits of the rank key
+    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
+    __syncthreads();
+    if (in_regs) {
+        load_batch(0, kreg);
+        if (S > SEL_T * U) {
+            load_batch(SEL_T * U, kreg + U);
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) kreg[U + u] = 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u)
+            if (kreg[u]) atomicAdd(&s_hist[kreg[u] >> 20], 1u);
+    } else {
+        for_each_sample([&](uint32_t k) { atomicAdd(&s_hist[k >> 20], 1u); });
+    }
+    __syncthreads();
+    find_cut_bin(s_hist, HBINS, r, s_tmp);
+    const int bin1 = s_tmp[16], above = s_tmp[17], found = s_tmp[19];
+    __syncthreads();
+    if (!found) {                                              // fewer than r samples can pass at all
+        if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
+        return;
+    }
+    // pass B: the next 12 bits inside that bin
+    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
+    __syncthreads();
+    if (in_regs) {
+#pragma unroll
+        for (int u = 0; u < 2 * U; ++u)
+            if (kreg[u] && (int)(kreg[u] >> 20) == bin1) atomicAdd(&s_hist[(kreg[u] >> 8) & 0xFFFu], 1u);
+    } else {
+        for_each_sample([&](uint32_t k) {
+            if ((int)(k >> 20) == bin1) atomicAdd(&s_hist[(k >> 8) & 0xFFFu], 1u);
+        });
+    }
+    __syncthreads();
+    find_cut_bin(s_hist, HBINS, r - above, s_tmp);
+    const int bin2 = s_tmp[16];
+    if (tid == 0) {
+        const uint32_t edge = ((uint32_t)bin1 << 20) | ((uint32_t)bin2 << 8);     // lower edge of the located bin
+        // 0.9999: below the score of every logit >= the bound even where the specified sigmoid is not monotone
+        const float cut = p.has_ctr ? u2f(edge) : spec_sigmoidf(from_ordered_bits(edge)) * 0.9999f;
+        if (cut > p.thresh && cut < 1.0f) {
+            float c = cut * 0.996f;                            // below every true score that rounds to >= cut
+            if (p.has_ctr) c = c * c;                          // sqrt(sig(cls) * sig(ctr)) >= cut needs sig(cls) >= cut^2
+            const float lg = logf(c / (1.0f - c));
+            float pre = lg - 0.01f * (1.0f + fabsf(lg));
+            if (p.prefilter && pre < p.pre_logit) pre = p.pre_logit;
+            out.cut = cut; out.pre = pre; out.active = 1;
+        }
+        cuts[(long long)b * p.num_levels + l] = out;
+    }
 }
 
 // Streams keys[0, total) through f(key) with 16 independent 16-byte loads per thread in flight: one
@@ -369,6 +538,9 @@ __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b
 __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_levels,
                                                        const unsigned long long* __restrict__ all_keys,
                                                        const unsigned int* __restrict__ key_count,
+                                                       const unsigned int* __restrict__ key_valid,
+                                                       const unsigned int* __restrict__ key_count_redo,
+                                                       const CutInfo* __restrict__ cuts,
                                                        const int* __restrict__ image_hw,
                                                        float* __restrict__ cand_boxes,
                                                        float* __restrict__ cand_scores,
@@ -380,9 +552,11 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y;
-    const unsigned int total = key_count[(long long)(b * num_levels + l) * CSTRIDE];
-    const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     const int K = p.topk;
+    const long long slot = (long long)b * num_levels + l;
+    unsigned int total = key_count[slot * CSTRIDE];
+    if (cuts[slot].active && key_valid[slot * CSTRIDE] < (unsigned int)K) total = key_count_redo[slot * CSTRIDE];
+    const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     if (total == 0) {
         if (tid == 0) cand_count[b * num_levels + l] = 0;
         return;
@@ -524,7 +698,8 @@ struct Layout {
     int chunk_start[OD_MAX_LEVELS + 1];
     long long key_off[OD_MAX_LEVELS];
     long long keys_per_image;
-    size_t keys_bytes, counts_bytes;
+    size_t keys_bytes, counts_bytes;               // counts: three counter arrays (reserved, valid, redo), then the cuts
+    size_t counter_bytes;                          // one counter array
 };
 
 bool make_layout(const int64_t* level_size, int num_levels, int batch, int num_classes, Layout* lay) {
@@ -544,7 +719,8 @@ bool make_layout(const int64_t* level_size, int num_levels, int batch, int num_c
     lay->total_chunks = (int)chunks;
     lay->keys_per_image = slots;
     lay->keys_bytes = ((size_t)batch * (size_t)slots * 8 + 255) & ~(size_t)255;
-    lay->counts_bytes = (size_t)batch * (size_t)num_levels * CSTRIDE * 4;
+    lay->counter_bytes = (size_t)batch * (size_t)num_levels * CSTRIDE * 4;
+    lay->counts_bytes = 3 * lay->counter_bytes + (((size_t)batch * (size_t)num_levels * sizeof(CutInfo) + 255) & ~(size_t)255);
     return true;
 }
 
@@ -586,12 +762,16 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
     hipStream_t s = (hipStream_t)stream;
     unsigned long long* keys = (unsigned long long*)workspace;
     unsigned int* key_count = (unsigned int*)((char*)workspace + lay.keys_bytes);
+    unsigned int* key_valid = (unsigned int*)((char*)key_count + lay.counter_bytes);
+    unsigned int* key_count_redo = (unsigned int*)((char*)key_valid + lay.counter_bytes);
+    CutInfo* cuts = (CutInfo*)((char*)key_count_redo + lay.counter_bytes);
 
     FilterParams fp;
     SelectParams sp;
     fp.num_levels = num_levels;
     fp.num_classes = num_classes;
     fp.has_ctr = bbox_ctrness ? 1 : 0;
+    fp.topk = topk;
     fp.total_chunks = lay.total_chunks;
     for (int l = 0; l <= OD_MAX_LEVELS; ++l) fp.chunk_start[l] = lay.chunk_start[l];
     for (int l = 0; l < OD_MAX_LEVELS; ++l) { fp.key_off[l] = lay.key_off[l]; sp.key_off[l] = lay.key_off[l]; }
@@ -658,16 +838,27 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
     sp.coder = coder;
     sp.clip = bbox_xform_clip;
 
-    OD_HIP(hipMemsetAsync(key_count, 0, lay.counts_bytes, s));
+    OD_HIP(hipMemsetAsync(key_count, 0, 3 * lay.counter_bytes, s));
+    bool sampled = false;                          // does any level get a sampled cut?
+    for (int l = 0; l < num_levels; ++l) sampled = sampled || fp.level_elems[l] >= SAMPLE_MIN;
+    OD_LAUNCH(OD_KERNEL_SAMPLE, s,
+              hipLaunchKernelGGL(sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, fp, cuts));
     if (lay.total_chunks > 0) {
+        const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
         OD_LAUNCH(OD_KERNEL_FILTER, s,
-                  hipLaunchKernelGGL(filter_kernel, dim3((unsigned)lay.total_chunks, (unsigned)batch), dim3(ST), 0, s,
-                                     fp, keys, key_count));
+                  hipLaunchKernelGGL(filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid, key_count_redo,
+                                     (const CutInfo*)cuts, 0));
+        if (sampled) {
+            OD_LAUNCH(OD_KERNEL_FILTER_REDO, s,
+                      hipLaunchKernelGGL(filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
+                                         key_count_redo, (const CutInfo*)cuts, 1));
+        }
     }
     OD_LAUNCH(OD_KERNEL_SELECT, s,
               hipLaunchKernelGGL(select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, sp,
                                  (int)num_levels, (const unsigned long long*)keys, (const unsigned int*)key_count,
-                                 image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count));
+                                 (const unsigned int*)key_valid, (const unsigned int*)key_count_redo,
+                                 (const CutInfo*)cuts, image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count));
     return OD_OK;
 }
 

@@ -480,3 +480,55 @@ def test_preprocess_images_matches_torch_transform(device, min_size, max_size, s
     if shapes[0] == (160, 160):
         want = (images[0] - torch.tensor(tr.image_mean)[:, None, None]) / torch.tensor(tr.image_std)[:, None, None]
         assert torch.equal(got.tensors[0].cpu(), want)              # identity resize: the normalized pixels themselves
+
+
+def _sampled_positions(E):
+    """Positions the candidate selection samples in a level of E logits (E >= 262144): the library's rule restated."""
+    S = (E // 64) & ~16383
+    S = min(max(S, 16384), 262144)
+    runs = S // 16
+    window = E // runs
+    run = np.arange(runs, dtype=np.uint64)
+    h = (run * np.uint64(2654435761)) & np.uint64(0xFFFFFFFF)
+    start = run * np.uint64(window) + ((h * np.uint64(window - 15)) >> np.uint64(32))
+    return (start[:, None] + np.arange(16, dtype=np.uint64)[None, :]).reshape(-1).astype(np.int64), S
+
+
+def test_select_sampled_bound_large_levels(device):
+    """Levels of at least 262144 logits estimate a score bound from a sample before filtering.  The result must be
+    the exact top-k whatever the sample says: (1) dense random logits (half of them pass a 0.05 threshold);
+    (2) thousands of saturated ties beyond K; (3) a level built so that the sample over-estimates the bound --
+    the best logits sit exactly on the sampled positions -- and the filter has to repeat the level without the bound;
+    (4) every logit equal; (5) threshold <= 0."""
+    gen = torch.Generator().manual_seed(2024)
+    N, C = 70001, 4                                           # E = 280004
+    dense = torch.empty((2, N, C)).normal_(-3.0, 1.5, generator=gen)
+    _check_select_single_level(device, dense, C, 0.05, 1000)
+    _check_select_single_level(device, dense, C, 0.5, 300)
+    ties = dense.clone()
+    ties[torch.rand((2, N, C), generator=gen) < 0.02] = 25.0            # ~5600 scores of exactly 1.0 per image
+    _check_select_single_level(device, ties, C, 0.5, 1000)
+    # (3): sampled positions hold the only high logits, so the r-th best sample is far above the true K-th best
+    E = N * C
+    pos, S = _sampled_positions(E)
+    assert S == 16384 and pos.max() < E and len(np.unique(pos)) == S
+    flat = torch.full((E,), -6.0)
+    others = torch.randperm(E, generator=gen)[:6000]
+    flat[others] = 0.1 + 0.9 * torch.rand(6000, generator=gen)          # pass the threshold, below every sample
+    flat[torch.from_numpy(pos)] = 2.0 + 4.0 * torch.rand(S, generator=gen)
+    extra = torch.randperm(E, generator=gen)[:300]
+    flat[extra] = 7.0                                                   # a few of the very best are not in the sample
+    adversarial = flat.view(1, N, C)
+    _check_select_single_level(device, adversarial, C, 0.5, 1000)
+    # the library's scratch buffer shows that the bound was active and left fewer than K valid keys (layout: key
+    # slots, then the reserved / valid / repeat counters 256 bytes apart, then 16 bytes of bound per (image, level))
+    ws = kernels._workspaces[(torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream, "select")]
+    keys_bytes = (((E + 31) & ~31) * 8 + 255) & ~255
+    counters = ws[keys_bytes:keys_bytes + 3 * 256].view(torch.int32).cpu()
+    bound = ws[keys_bytes + 3 * 256:keys_bytes + 3 * 256 + 16].cpu()
+    assert int(bound.view(torch.int32)[2]) == 1, "sampled bound inactive"
+    assert 0 < int(counters[64]) < 1000 and int(counters[128]) >= S, counters[[0, 64, 128]].tolist()
+    _check_select_single_level(device, adversarial, C, 0.5, 4096)
+    _check_select_single_level(device, torch.full((1, N, C), 0.25), C, 0.5, 1000)
+    _check_select_single_level(device, dense[:1], C, 0.0, 500)
+    _check_select_single_level(device, dense[:1], C, -1.0, 500)
