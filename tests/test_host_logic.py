@@ -120,3 +120,28 @@ def test_shard_bounds_and_pack():
     assert dets[1]["boxes"].shape == (0, 4)
     g, c = sharding.all_gather_detections(packed, torch.tensor([3, 0]))     # no process group: identity
     assert g is packed
+
+
+def test_transform_host_size_and_ratio_rules():
+    """Host-side rules the fused transform relies on: the resized size equals what torch's interpolate produces for
+    the same scale factor, box ratios equal the fp32 quotient torchvision forms with tensors, and the head's
+    channel-major maps hold the same values as its permuted outputs."""
+    from object_detection_amd import transform as T
+    tr = GeneralizedRCNNTransform(97, 131, [0.5] * 3, [0.25] * 3)
+    for h, w in [(100, 80), (50, 90), (333, 77), (97, 131), (640, 480), (31, 1000)]:
+        want = tuple(tr.resize(torch.zeros(3, h, w), None)[0].shape[-2:])
+        assert tr._resized_size(h, w) == want, (h, w)
+    boxes = torch.tensor([[3.0, 7.0, 40.5, 91.25], [0.0, 0.0, 1.0, 1.0]])
+    for old, new in [((100, 80), (64, 51)), ((333, 77), (97, 22)), ((97, 131), (97, 131))]:
+        ratios = [torch.tensor(s, dtype=torch.float32) / torch.tensor(o, dtype=torch.float32) for s, o in zip(new, old)]
+        xmin, ymin, xmax, ymax = boxes.unbind(1)
+        want = torch.stack((xmin * ratios[1], ymin * ratios[0], xmax * ratios[1], ymax * ratios[0]), dim=1)
+        assert torch.equal(T.resize_boxes(boxes, old, new), want)
+    head = RetinaNetHead(32, 9, 4)
+    feats = list(PyramidStub(3, 32)(torch.rand(2, 3, 64, 64)).values())
+    maps, out = head.forward_maps(feats), head(feats)
+    first = maps["cls_logits"][0]                         # [2, 9*4, 16, 16]
+    assert first.shape == (2, 36, 16, 16)
+    hw, a, c = 5 * 16 + 3, 7, 2                           # location (5, 3), anchor 7, class 2
+    assert out["cls_logits"][1, hw * 9 + a, c] == first[1, a * 4 + c, 5, 3]
+    assert out["bbox_regression"][0, hw * 9 + a, 1] == maps["bbox_regression"][0][0, a * 4 + 1, 5, 3]
