@@ -43,17 +43,16 @@ def all_gather_detections(packed: Tensor, counts: Tensor, group=None) -> Tuple[T
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return packed, counts
     world = dist.get_world_size(group)
-    packed = packed.contiguous()
-    counts = counts.contiguous()
-    g_packed = packed.new_empty((world * packed.shape[0],) + tuple(packed.shape[1:]))
-    g_counts = counts.new_empty((world * counts.shape[0],))
+    B = packed.shape[0]
+    # one message per rank: the detections of an image followed by its count (exact in fp32: counts <= D < 2^24)
+    local = torch.cat((packed.reshape(B, -1), counts.to(packed.dtype).reshape(B, 1)), dim=1).contiguous()
+    gathered = local.new_empty((world * B, local.shape[1]))
     try:
-        dist.all_gather_into_tensor(g_packed, packed, group=group)
-        dist.all_gather_into_tensor(g_counts, counts, group=group)
+        dist.all_gather_into_tensor(gathered, local, group=group)
     except (RuntimeError, NotImplementedError):   # backends without the flat form
-        parts = [torch.empty_like(packed) for _ in range(world)]
-        cparts = [torch.empty_like(counts) for _ in range(world)]
-        dist.all_gather(parts, packed, group=group)
-        dist.all_gather(cparts, counts, group=group)
-        g_packed, g_counts = torch.cat(parts), torch.cat(cparts)
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        gathered = torch.cat(parts)
+    g_packed = gathered[:, :-1].reshape((world * B,) + tuple(packed.shape[1:]))
+    g_counts = gathered[:, -1].to(counts.dtype)
     return g_packed, g_counts
