@@ -62,6 +62,8 @@ def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
         "match_heavy": 0.0,                              # tiles of match_assign done cooperatively: its bytes are counted there
         "match_flag": 4.0 * B * M,
         "match_restore": 0.0,                            # patches a few anchors; no mandatory traffic
+        "sample": 0.0,                                   # reads a 1/64 sample of the large levels; no mandatory traffic
+        "filter_redo": 0.0,                              # repeats a level only when its sampled bound was too high
         "nms": B * (28.0 * n_cand_per_image + 8.0 * D),
         "anchor": 16.0 * N,
     }.get(kernel, 0.0)
@@ -114,6 +116,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3, 4),
                     help="2: the inference half and the training half of a step run on HIP streams of their own; "
                          "3: in addition the inference halves of consecutive steps alternate between two streams")
+    ap.add_argument("--lean", action="store_true",
+                    help="only warm-up, kernel probe and the timed region (for profiling: the kernel statistics of the "
+                         "run are then those of the timed region); the secondary figures are reported as null")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -218,7 +223,10 @@ def main():
     n_cand = float(kernels_candidates_per_image(cfg, split, split_anchors, shapes, model))
     dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"])
     dom_id = _C.KERNEL_NAMES.index(dominant)
+    # In the timed region every 8th launch of the dominant kernel is timed (start / stop events on the dispatch):
+    # a timed launch costs the host tens of microseconds, which would otherwise end up in `value`.
     _C.profile_select(dom_id)
+    _C.profile_stride(8)
     _C.profile_read(dom_id)
 
     sync()
@@ -231,15 +239,18 @@ def main():
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = _C.profile_read(dom_id)
     _C.profile_select(_C.PROFILE_OFF)
+    _C.profile_stride(1)
 
     # for reference: the same step with a blocking host read of the counts after every step (not `value`)
-    step(sync_host=True)
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(20):
+    ms_host_sync = None
+    if not args.lean:
         step(sync_host=True)
-    sync()
-    ms_host_sync = 1e3 * (time.perf_counter() - t1) / 20
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            step(sync_host=True)
+        sync()
+        ms_host_sync = 1e3 * (time.perf_counter() - t1) / 20
 
     # the two halves on their own (they never run in the same forward of the reference): 20 launches each
     def half(fn):
@@ -251,11 +262,13 @@ def main():
         sync()
         return 1e3 * (time.perf_counter() - th) / 20
 
-    ms_post = half(lambda: postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
-                                               model.score_thresh, model.topk_candidates, model.nms_thresh,
-                                               model.detections_per_img, _C.CODER_BOXCODER,
-                                               model.box_coder.bbox_xform_clip, return_padded=True))
-    ms_match = half(lambda: model.match_anchors(targets, anchors_per_image))
+    ms_post = ms_match = None
+    if not args.lean:
+        ms_post = half(lambda: postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
+                                                   model.score_thresh, model.topk_candidates, model.nms_thresh,
+                                                   model.detections_per_img, _C.CODER_BOXCODER,
+                                                   model.box_coder.bbox_xform_clip, return_padded=True))
+        ms_match = half(lambda: model.match_anchors(targets, anchors_per_image))
 
     if world > 1:
         import torch.distributed as dist
@@ -283,7 +296,7 @@ def main():
             "ms_per_step_blocking_host_read": ms_host_sync,
             "ms_per_step_host_enqueue": 1e3 * host_enqueue / args.steps,
             "detections_per_step": total_detections / args.steps,
-            "phases": {
+            "phases": None if args.lean else {
                 "postprocess_ms": ms_post, "postprocess_images_per_s": cfg.batch / (ms_post * 1e-3),
                 "match_ms": ms_match, "match_images_per_s": cfg.batch / (ms_match * 1e-3),
                 # brute-force equivalent: every (anchor, GT) pair of the batch counts, although the kernels

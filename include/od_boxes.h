@@ -254,7 +254,8 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 /*
  * Per-kernel timing aid.  No counterpart in the reference (it has no profiling hooks); used by
  * bench.py to measure a kernel's own duration on the stream it runs on.  od_profile_select makes the
- * library bracket every later launch of that kernel (or of all kernels) with hipEvents;
+ * library launch that kernel (or all kernels) with a start and a stop event that receive the dispatch's own
+ * begin / end time stamps (hipExtLaunchKernel) -- the duration a kernel trace reports;
  * od_profile_read waits for those events, returns the summed elapsed milliseconds and the number of
  * launches since the previous read, and resets the kernel's counters.
  */
@@ -281,6 +282,9 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_FILTER_REDO 18    /* od_select_candidates: second filter pass (normally exits at once) */
 #define OD_KERNEL_COUNT 19
 int od_profile_select(int32_t kernel_id);
+/* Time only every `every`-th launch of a selected kernel (default 1): a timed launch costs the host tens of
+ * microseconds, which a throughput measurement should not pay on every step. */
+int od_profile_stride(int32_t every);
 int od_profile_read(int32_t kernel_id, double* total_ms, int64_t* launches);
 
 #ifdef __cplusplus

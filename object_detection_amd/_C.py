@@ -60,6 +60,7 @@ SIGNATURES = {
                                        _P, c_float, c_float, _P, _P, _P, _P]),
     "od_preprocess_images": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
     "od_profile_select": (c_int32, [c_int32]),
+    "od_profile_stride": (c_int32, [c_int32]),
     "od_profile_read": (c_int32, [c_int32, _P, _P]),
 }
 
@@ -104,6 +105,11 @@ def check(code: int, what: str) -> None:
 
 def profile_select(kernel_id: int) -> None:
     check(lib().od_profile_select(int(kernel_id)), "od_profile_select")
+
+
+def profile_stride(every: int) -> None:
+    """Time only every ``every``-th launch of the selected kernel(s)."""
+    check(lib().od_profile_stride(int(every)), "od_profile_stride")
 
 
 def profile_read(kernel_id: int):

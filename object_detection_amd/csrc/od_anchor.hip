@@ -73,8 +73,7 @@ extern "C" int od_anchor_generate(const int32_t* grid_h, const int32_t* grid_w, 
     if (n_total == 0) return OD_OK;
     if (((uintptr_t)out & 15) != 0) return OD_ERR_ARG;
     unsigned blocks = (unsigned)((n_total + 255) / 256);
-    OD_LAUNCH(OD_KERNEL_ANCHOR, (hipStream_t)stream,
-              hipLaunchKernelGGL(anchor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p,
-                                 reinterpret_cast<float4*>(out), (long long)n_total));
+    OD_LAUNCH_KERNEL(OD_KERNEL_ANCHOR, anchor_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p,
+                     reinterpret_cast<float4*>(out), (long long)n_total);
     return OD_OK;
 }

@@ -3,7 +3,11 @@
 // correctly rounded fp32 division and sqrt, fp32 denormals preserved (hipcc defaults).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+
+#include <tuple>
+#include <utility>
 
 #define OD_OK 0
 #define OD_ERR_ARG (-1)        // null pointer / negative size / inconsistent shapes
@@ -22,21 +26,44 @@
         if (e__ != hipSuccess) return (int)e__;   \
     } while (0)
 
-// Launch `call` (a hipLaunchKernelGGL expression) as kernel `id`, bracketed by events when profiling selects it.
-#define OD_LAUNCH(id, stream, call)                        \
-    do {                                                   \
-        void* tok__ = nullptr;                             \
-        od::profile_begin((id), (stream), &tok__);         \
-        call;                                              \
-        od::profile_end(tok__, (stream));                  \
-        OD_LAUNCH_CHECK();                                 \
+namespace od {
+
+// Per-kernel timing (od_profile.hip): true when launches of `kernel_id` are being timed; *start / *stop are then
+// the events that receive the kernel's own begin and end time stamps.
+bool profile_events(int kernel_id, hipEvent_t* start, hipEvent_t* stop);
+
+// hipExtLaunchKernel with the arguments converted to the kernel's parameter types: the start / stop events take
+// the time stamps of the dispatch itself (what a kernel trace shows), not those of markers around it.
+template <typename... K, typename... A, size_t... I>
+inline hipError_t launch_timed_impl(void (*kernel)(K...), dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                                    hipEvent_t start, hipEvent_t stop, std::index_sequence<I...>, A&&... args) {
+    std::tuple<K...> params(static_cast<K>(std::forward<A>(args))...);
+    void* ptrs[] = {(void*)&std::get<I>(params)...};
+    return hipExtLaunchKernel((const void*)kernel, grid, block, ptrs, shmem, s, start, stop, 0);
+}
+template <typename... K, typename... A>
+inline hipError_t launch_timed(void (*kernel)(K...), dim3 grid, dim3 block, size_t shmem, hipStream_t s,
+                               hipEvent_t start, hipEvent_t stop, A&&... args) {
+    static_assert(sizeof...(K) == sizeof...(A), "one argument per kernel parameter");
+    return launch_timed_impl(kernel, grid, block, shmem, s, start, stop, std::index_sequence_for<K...>{},
+                             std::forward<A>(args)...);
+}
+
+}  // namespace od
+
+// Launches kernel `id`; when profiling selects it, through the timed form.
+#define OD_LAUNCH_KERNEL(id, kernel, grid, block, shmem, stream, ...)                                       \
+    do {                                                                                                    \
+        hipEvent_t ea__ = nullptr, eb__ = nullptr;                                                          \
+        if (od::profile_events((id), &ea__, &eb__)) {                                                       \
+            OD_HIP(od::launch_timed(kernel, grid, block, shmem, stream, ea__, eb__, __VA_ARGS__));          \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                            \
+        }                                                                                                   \
+        OD_LAUNCH_CHECK();                                                                                  \
     } while (0)
 
 namespace od {
-
-// optional event bracketing of kernel launches (od_profile.hip); token is null when not selected
-bool profile_begin(int kernel_id, hipStream_t s, void** token);
-void profile_end(void* token, hipStream_t s);
 
 constexpr int kWave = 64;
 

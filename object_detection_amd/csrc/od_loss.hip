@@ -661,8 +661,9 @@ extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int6
     int* part_fg = (int*)((char*)workspace + part);
     if (blocks > 0) {
         const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_FOCAL_FWD(G2, T) \
-    OD_LAUNCH(OD_KERNEL_FOCAL_FWD, s, hipLaunchKernelGGL((focal_forward_kernel<G2, T>), grid, dim3(LT), 0, s, a, part_loss, part_fg))
+#define OD_FOCAL_FWD(G2, T)                                                                                  \
+    OD_LAUNCH_KERNEL(OD_KERNEL_FOCAL_FWD, (focal_forward_kernel<G2, T>), grid, dim3(LT), 0, s, a, part_loss, \
+                     part_fg)
         if (gamma == 2.0f) {
             if (dtype == OD_DTYPE_F32) { OD_FOCAL_FWD(true, float); }
             else if (dtype == OD_DTYPE_F16) { OD_FOCAL_FWD(true, _Float16); }
@@ -698,10 +699,9 @@ extern "C" int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int
     if (blocks == 0) return OD_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_FOCAL_BWD(G2, T)                                                                                       \
-    OD_LAUNCH(OD_KERNEL_FOCAL_BWD, s,                                                                             \
-              hipLaunchKernelGGL((focal_backward_kernel<G2, T>), grid, dim3(LT), 0, s, a, num_foreground, grad_loss, \
-                                 (int)batch, (T*)grad_logits))
+#define OD_FOCAL_BWD(G2, T)                                                                                      \
+    OD_LAUNCH_KERNEL(OD_KERNEL_FOCAL_BWD, (focal_backward_kernel<G2, T>), grid, dim3(LT), 0, s, a, num_foreground, \
+                     grad_loss, (int)batch, (T*)grad_logits)
     if (gamma == 2.0f) {
         if (dtype == OD_DTYPE_F32) { OD_FOCAL_BWD(true, float); }
         else if (dtype == OD_DTYPE_F16) { OD_FOCAL_BWD(true, _Float16); }
@@ -743,8 +743,9 @@ extern "C" int od_box_loss_forward(const void* bbox_regression, int32_t dtype, i
     int* part_fg = (int*)((char*)workspace + part);
     if (blocks > 0) {
         const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_BOX_FWD(T) \
-    OD_LAUNCH(OD_KERNEL_BOX_LOSS_FWD, s, hipLaunchKernelGGL((box_loss_forward_kernel<T>), grid, dim3(RT), 0, s, a, part_loss, part_fg))
+#define OD_BOX_FWD(T)                                                                                         \
+    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_FWD, (box_loss_forward_kernel<T>), grid, dim3(RT), 0, s, a, part_loss, \
+                     part_fg)
         if (dtype == OD_DTYPE_F32) { OD_BOX_FWD(float); }
         else if (dtype == OD_DTYPE_F16) { OD_BOX_FWD(_Float16); }
         else { OD_BOX_FWD(bf16_t); }
@@ -775,10 +776,9 @@ extern "C" int od_box_loss_backward(const void* bbox_regression, int32_t dtype, 
     if (blocks == 0) return OD_OK;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_BOX_BWD(T)                                                                                                \
-    OD_LAUNCH(OD_KERNEL_BOX_LOSS_BWD, s,                                                                             \
-              hipLaunchKernelGGL((box_loss_backward_kernel<T>), grid, dim3(RT), 0, s, a, num_foreground, grad_loss, \
-                                 (int)batch, (T*)grad_regression))
+#define OD_BOX_BWD(T)                                                                                             \
+    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_BWD, (box_loss_backward_kernel<T>), grid, dim3(RT), 0, s, a, num_foreground, \
+                     grad_loss, (int)batch, (T*)grad_regression)
     if (dtype == OD_DTYPE_F32) { OD_BOX_BWD(float); }
     else if (dtype == OD_DTYPE_F16) { OD_BOX_BWD(_Float16); }
     else { OD_BOX_BWD(bf16_t); }

@@ -723,29 +723,26 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
     if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total * GSTRIDE, s));
     OD_HIP(hipMemsetAsync(ws.any_flag, 0, 256 + (size_t)batch * 128, s));
-    OD_LAUNCH(OD_KERNEL_MATCH_ASSIGN, s,
-              hipLaunchKernelGGL(match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors,
-                                 (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
-                                 gt_offsets, ws, restore, high, low, (long long*)matched));
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, (long
+                     long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore,
+                     high, low, (long long*)matched);
     if (m_total > HEAVY) {
         int heavy_y = 4096 / batch > 64 ? 4096 / batch : 64;
         if (heavy_y > wtiles) heavy_y = wtiles;
-        OD_LAUNCH(OD_KERNEL_MATCH_HEAVY, s,
-                  hipLaunchKernelGGL(match_heavy_kernel, dim3((unsigned)batch, (unsigned)heavy_y), dim3(HT), 0, s, (const float4*)anchors,
-                                     (long long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes,
-                                     gt_offsets, ws, restore, high, low, (long long*)matched));
+        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_HEAVY, match_heavy_kernel, dim3((unsigned)batch, (unsigned)heavy_y),
+                         dim3(HT), 0, s, (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, wtiles,
+                         (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
-        OD_LAUNCH(OD_KERNEL_MATCH_FLAG, s,
-                  hipLaunchKernelGGL(match_flag_kernel, dim3((unsigned)batch), dim3(64), 0, s, gt_offsets, ws));
+        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FLAG, match_flag_kernel, dim3((unsigned)batch), dim3(64), 0, s, gt_offsets,
+                         ws);
         const long long light_threads = total_tiles * LCAP;
         const int light_blocks = (int)((light_threads + 255) / 256 < 8192 ? (light_threads + 255) / 256 : 8192);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
-        OD_LAUNCH(OD_KERNEL_MATCH_RESTORE, s,
-                  hipLaunchKernelGGL(match_restore_kernel, dim3((unsigned)(light_blocks + heavy_entry_blocks)), dim3(256), 0,
-                                     s, (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, wtiles,
-                                     (int)batch, light_blocks, (const float4*)gt_boxes, gt_offsets, ws,
-                                     (long long*)matched));
+        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel, dim3((unsigned)(light_blocks +
+                         heavy_entry_blocks)), dim3(256), 0, s, (const float4*)anchors, (long
+                         long)anchor_batch_stride, (long long)n, wtiles, (int)batch, light_blocks, (const
+                         float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
     }
     return OD_OK;
 }
@@ -761,11 +758,10 @@ extern "C" int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, 
     if (n_first_level < 0 || n_last_level < 0 || n_first_level > n || n_last_level > n) return OD_ERR_ARG;
     if (batch > 65535) return OD_ERR_LIMIT;
     dim3 grid((unsigned)((n + FT - 1) / FT), (unsigned)batch);
-    OD_LAUNCH(OD_KERNEL_MATCH_FCOS, (hipStream_t)stream,
-              hipLaunchKernelGGL(match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream, (const float4*)anchors,
-                                 (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
-                                 (long long)n_last_level, (const float4*)gt_boxes, gt_offsets,
-                                 center_sampling_radius, (long long*)matched));
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FCOS, match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream, (const
+                     float4*)anchors, (long long)anchor_batch_stride, (long long)n, (long long)n_first_level, (long
+                     long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius, (long
+                     long*)matched);
     return OD_OK;
 }
 
@@ -776,9 +772,8 @@ extern "C" int od_box_iou(const float* boxes1, int64_t m, const float* boxes2, i
     if (((uintptr_t)boxes1 & 15) || ((uintptr_t)boxes2 & 15)) return OD_ERR_ARG;
     if (m > 65535) return OD_ERR_LIMIT;
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)m);
-    OD_LAUNCH(OD_KERNEL_BOX_IOU, (hipStream_t)stream,
-              hipLaunchKernelGGL(box_iou_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float4*)boxes1,
-                                 (long long)m, (const float4*)boxes2, (long long)n, out));
+    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_IOU, box_iou_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const
+                     float4*)boxes1, (long long)m, (const float4*)boxes2, (long long)n, out);
     return OD_OK;
 }
 
@@ -797,12 +792,10 @@ extern "C" int od_matcher(const float* quality, int64_t m, int64_t n, float high
     if (m > 0x7fffffff) return OD_ERR_LIMIT;
     hipStream_t s = (hipStream_t)stream;
     float* rowmax = (float*)workspace;
-    OD_LAUNCH(OD_KERNEL_MATCHER, s,
-              hipLaunchKernelGGL(matcher_rowmax_kernel, dim3((unsigned)m), dim3(256), 0, s, quality, (long long)n,
-                                 rowmax));
-    OD_LAUNCH(OD_KERNEL_MATCHER, s,
-              hipLaunchKernelGGL(matcher_col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, quality,
-                                 (long long)m, (long long)n, rowmax, high, low, allow_low_quality ? 1 : 0,
-                                 (long long*)matches));
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCHER, matcher_rowmax_kernel, dim3((unsigned)m), dim3(256), 0, s, quality, (long
+                     long)n, rowmax);
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCHER, matcher_col_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                     quality, (long long)m, (long long)n, rowmax, high, low, allow_low_quality ? 1 : 0, (long
+                     long*)matches);
     return OD_OK;
 }

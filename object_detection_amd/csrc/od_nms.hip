@@ -581,7 +581,6 @@ extern "C" int od_batched_nms(const float* boxes, const float* scores, const int
         OD_HIP(hipMemsetAsync(out_count, 0, sizeof(int) * (size_t)batch, (hipStream_t)stream));
         return OD_OK;
     }
-    OD_LAUNCH(OD_KERNEL_NMS, (hipStream_t)stream,
-              hipLaunchKernelGGL(nms_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a));
+    OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
     return OD_OK;
 }

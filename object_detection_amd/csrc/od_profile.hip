@@ -1,6 +1,8 @@
-// Optional per-kernel timing: when enabled, the library brackets the launches of the selected kernel
-// with hipEvents recorded on the caller's stream, so a benchmark can read the kernel's own duration
-// (not host-side wall time) without an external profiler.  Off by default; costs nothing when off.
+// Optional per-kernel timing: when enabled, the library launches the selected kernel through
+// hipExtLaunchKernel with a start and a stop event, which receive the time stamps of the dispatch itself, so a
+// benchmark can read the kernel's own duration (what a kernel trace reports; not host-side wall time, and not the
+// distance between marker events, which also contains the gaps around the kernel) without an external profiler.
+// Off by default; costs nothing when off.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -13,28 +15,26 @@ struct EventPair { hipEvent_t a, b; };
 
 static std::mutex g_mu;
 static int g_selected = OD_PROFILE_OFF;
+static int g_every = 1;                                  // time every g_every-th launch of a selected kernel
+static long long g_seen[OD_KERNEL_COUNT];
 static std::vector<EventPair> g_pool[OD_KERNEL_COUNT];   // created once, reused after each read
 static size_t g_used[OD_KERNEL_COUNT];
 
-bool profile_begin(int kernel_id, hipStream_t s, void** token) {
-    *token = nullptr;
+bool profile_events(int kernel_id, hipEvent_t* start, hipEvent_t* stop) {
     if (g_selected == OD_PROFILE_OFF) return false;
     if (g_selected != OD_PROFILE_ALL && g_selected != kernel_id) return false;
     std::lock_guard<std::mutex> lk(g_mu);
+    if (g_seen[kernel_id]++ % g_every != 0) return false;
     if (g_used[kernel_id] == g_pool[kernel_id].size()) {
         EventPair p;
         if (hipEventCreate(&p.a) != hipSuccess) return false;
         if (hipEventCreate(&p.b) != hipSuccess) { (void)hipEventDestroy(p.a); return false; }
         g_pool[kernel_id].push_back(p);
     }
-    EventPair& p = g_pool[kernel_id][g_used[kernel_id]++];
-    (void)hipEventRecord(p.a, s);
-    *token = &p;   // stable until the next push_back of the same id, which cannot happen before profile_end
+    const EventPair& p = g_pool[kernel_id][g_used[kernel_id]++];
+    *start = p.a;
+    *stop = p.b;
     return true;
-}
-
-void profile_end(void* token, hipStream_t s) {
-    if (token) (void)hipEventRecord(static_cast<EventPair*>(token)->b, s);
 }
 
 }  // namespace od
@@ -44,6 +44,14 @@ extern "C" int od_profile_select(int32_t kernel_id) {
         return OD_ERR_ARG;
     std::lock_guard<std::mutex> lk(od::g_mu);
     od::g_selected = kernel_id;
+    return OD_OK;
+}
+
+extern "C" int od_profile_stride(int32_t every) {
+    if (every < 1) return OD_ERR_ARG;
+    std::lock_guard<std::mutex> lk(od::g_mu);
+    od::g_every = every;
+    for (int k = 0; k < OD_KERNEL_COUNT; ++k) od::g_seen[k] = 0;
     return OD_OK;
 }
 

@@ -841,24 +841,21 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
     OD_HIP(hipMemsetAsync(key_count, 0, 3 * lay.counter_bytes, s));
     bool sampled = false;                          // does any level get a sampled cut?
     for (int l = 0; l < num_levels; ++l) sampled = sampled || fp.level_elems[l] >= SAMPLE_MIN;
-    OD_LAUNCH(OD_KERNEL_SAMPLE, s,
-              hipLaunchKernelGGL(sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, fp, cuts));
+    OD_LAUNCH_KERNEL(OD_KERNEL_SAMPLE, sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,
+                     fp, cuts);
     if (lay.total_chunks > 0) {
         const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
-        OD_LAUNCH(OD_KERNEL_FILTER, s,
-                  hipLaunchKernelGGL(filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid, key_count_redo,
-                                     (const CutInfo*)cuts, 0));
+        OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
+                         key_count_redo, (const CutInfo*)cuts, 0);
         if (sampled) {
-            OD_LAUNCH(OD_KERNEL_FILTER_REDO, s,
-                      hipLaunchKernelGGL(filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
-                                         key_count_redo, (const CutInfo*)cuts, 1));
+            OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count,
+                             key_valid, key_count_redo, (const CutInfo*)cuts, 1);
         }
     }
-    OD_LAUNCH(OD_KERNEL_SELECT, s,
-              hipLaunchKernelGGL(select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, sp,
-                                 (int)num_levels, (const unsigned long long*)keys, (const unsigned int*)key_count,
-                                 (const unsigned int*)key_valid, (const unsigned int*)key_count_redo,
-                                 (const CutInfo*)cuts, image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count));
+    OD_LAUNCH_KERNEL(OD_KERNEL_SELECT, select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,
+                     sp, (int)num_levels, (const unsigned long long*)keys, (const unsigned int*)key_count,
+                     (const unsigned int*)key_valid, (const unsigned int*)key_count_redo, (const CutInfo*)cuts,
+                     image_hw, cand_boxes, cand_scores, cand_labels, (long long*)cand_index, cand_count);
     return OD_OK;
 }
 
@@ -903,9 +900,8 @@ extern "C" int od_decode_boxes(const float* rel_codes, const float* boxes, int64
     if (!rel_codes || !boxes || !out) return OD_ERR_ARG;
     if (((uintptr_t)rel_codes & 15) || ((uintptr_t)boxes & 15) || ((uintptr_t)out & 15)) return OD_ERR_ARG;
     if (coder != OD_CODER_BOXCODER && coder != OD_CODER_LINEAR) return OD_ERR_ARG;
-    OD_LAUNCH(OD_KERNEL_DECODE, (hipStream_t)stream,
-              hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                                 (const float4*)rel_codes, (const float4*)boxes, (long long)n, (int)coder,
-                                 bbox_xform_clip, clip_h, clip_w, (float4*)out));
+    OD_LAUNCH_KERNEL(OD_KERNEL_DECODE, decode_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)rel_codes, (const float4*)boxes, (long long)n, (int)coder,
+                     bbox_xform_clip, clip_h, clip_w, (float4*)out);
     return OD_OK;
 }

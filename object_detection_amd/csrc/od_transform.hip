@@ -123,7 +123,7 @@ extern "C" int od_preprocess_images(const float* const* images, const int32_t* i
         p.out_w = out_w;
         float* dst = out + (long long)first * channels * out_h * out_w;
         const dim3 grid((unsigned)((out_w + 255) / 256), (unsigned)((out_h + 3) / 4), (unsigned)(count * channels));
-        OD_LAUNCH(OD_KERNEL_PREPROCESS, s, hipLaunchKernelGGL(prep_kernel, grid, dim3(256), 0, s, p, dst, vec_ok));
+        OD_LAUNCH_KERNEL(OD_KERNEL_PREPROCESS, prep_kernel, grid, dim3(256), 0, s, p, dst, vec_ok);
     }
     return OD_OK;
 }

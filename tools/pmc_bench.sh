@@ -15,12 +15,19 @@ root = os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/pmc_bench"
 out = {}
 for name in ("fetch", "write"):
     agg, cnt = collections.defaultdict(float), collections.Counter()
+    rows = []
     for f in glob.glob(f"{root}/{name}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0].replace("(anonymous namespace)::", "").strip()
             if "anonymous namespace" in r["Kernel_Name"]:
                 k = r["Kernel_Name"].split("::")[1].split("(")[0]
-            agg[k] += float(r["Counter_Value"]); cnt[k] += 1
+            rows.append((k, float(r["Counter_Value"])))
+    # the score filter is launched twice per call; its second launch (redo pass, normally a no-op) is listed apart
+    top = max([v for k, v in rows if k == "filter_kernel"], default=0.0)
+    for k, v in rows:
+        if k == "filter_kernel" and v < 0.05 * top:
+            k = "filter_kernel(redo pass)"
+        agg[k] += v; cnt[k] += 1
     for k in agg:
         out.setdefault(k, {})[name + "_KiB_per_launch"] = agg[k] / cnt[k]
         out[k]["launches_" + name] = cnt[k]
