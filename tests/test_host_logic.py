@@ -145,3 +145,26 @@ def test_transform_host_size_and_ratio_rules():
     hw, a, c = 5 * 16 + 3, 7, 2                           # location (5, 3), anchor 7, class 2
     assert out["cls_logits"][1, hw * 9 + a, c] == first[1, a * 4 + c, 5, 3]
     assert out["bbox_regression"][0, hw * 9 + a, 1] == maps["bbox_regression"][0][0, a * 4 + 1, 5, 3]
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """The reference's checkpoint dictionary ({'weights', 'height', 'width'}) written and read back; the head entries
+    load into a freshly initialised model by their torchvision names, a shape mismatch is reported."""
+    from object_detection_amd import checkpoint
+    a = get_model(4, backbone="pyramid_stub", layers=[0], out_channels=32)
+    b = get_model(4, backbone="pyramid_stub", layers=[0], out_channels=32)
+    path = str(tmp_path / "model.pt")
+    checkpoint.save_checkpoint(a, path, 1024, 1024)
+    params = checkpoint.load_checkpoint(path)
+    assert params["height"] == 1024 and params["width"] == 1024
+    loaded, missing = checkpoint.load_weights(b, params["weights"])
+    assert not missing and "head.classification_head.cls_logits.weight" in loaded
+    for name, t in a.state_dict().items():
+        if name.startswith("head."):
+            assert torch.equal(t, b.state_dict()[name]), name
+    other = get_model(7, backbone="pyramid_stub", layers=[0], out_channels=32)       # another class count
+    with pytest.raises(ValueError, match="cls_logits"):
+        checkpoint.load_weights(other, params["weights"])
+    torch.save([1, 2, 3], path)
+    with pytest.raises(ValueError):
+        checkpoint.load_checkpoint(path)
