@@ -24,8 +24,13 @@ def _require_gpu(t: Tensor, name: str) -> None:
                            f"(got device {t.device})")
 
 
+def _raw_stream(device: torch.device) -> int:
+    """Handle of the current HIP stream of ``device`` (the integer torch keeps; no Stream object is built)."""
+    return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 def _stream(device: torch.device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return ctypes.c_void_p(_raw_stream(device))
 
 
 def _ptr(t: Optional[Tensor]) -> ctypes.c_void_p:
@@ -37,7 +42,7 @@ def _workspace(device: torch.device, tag: str, nbytes: int) -> Tensor:
 
     Keyed by the current stream as well: calls enqueued on different streams may run concurrently and
     must not share scratch memory."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device.index, _raw_stream(device), tag)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -213,9 +218,34 @@ class SelectPlan:
 _plans: Dict[tuple, SelectPlan] = {}
 
 
+_candidate_buffers: Dict[tuple, tuple] = {}
+
+
+def _candidate_outputs(dev: torch.device, B: int, L: int, K: int, want_index: bool, reuse: bool):
+    """Output tensors of the candidate selection.  ``reuse``: per-stream buffers that the next call on the same
+    stream overwrites -- for callers that consume the candidates at once on that stream (postprocess: the NMS call
+    that follows), so that a step does not allocate five intermediate tensors."""
+    key = (dev.index, _raw_stream(dev), B, L, K) if reuse and not want_index else None
+    if key is not None:
+        bufs = _candidate_buffers.get(key)
+        if bufs is not None:
+            return bufs
+    bufs = (torch.empty((B, L * K, 4), dtype=torch.float32, device=dev),
+            torch.empty((B, L * K), dtype=torch.float32, device=dev),
+            torch.empty((B, L * K), dtype=torch.int32, device=dev),
+            torch.empty((B, L * K), dtype=torch.int64, device=dev) if want_index else None,
+            torch.empty((B, L), dtype=torch.int32, device=dev))
+    if key is not None:
+        if len(_candidate_buffers) > 64:
+            _candidate_buffers.clear()
+        _candidate_buffers[key] = bufs
+    return bufs
+
+
 def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor], anchor_levels: Sequence[Tensor],
                       image_hw: Tensor, score_thresh: float, topk: int, coder: int, bbox_xform_clip: float,
-                      ctr_levels: Optional[Sequence[Tensor]] = None, want_index: bool = False):
+                      ctr_levels: Optional[Sequence[Tensor]] = None, want_index: bool = False,
+                      reuse_outputs: bool = False):
     """Score filter + top-k + decode + clip for all (image, level).
 
     cls_levels[l]: [B, N_l, C]; reg_levels[l]: [B, N_l, 4]; anchor_levels[l]: [N_l, 4] (shared by the
@@ -258,11 +288,8 @@ def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor]
     if ctr_levels is not None:
         ctr_t, ctr_s = prep(ctr_levels, 1)
     K = int(topk)
-    cand_boxes = torch.empty((B, L * K, 4), dtype=torch.float32, device=dev)
-    cand_scores = torch.empty((B, L * K), dtype=torch.float32, device=dev)
-    cand_labels = torch.empty((B, L * K), dtype=torch.int32, device=dev)
-    cand_index = torch.empty((B, L * K), dtype=torch.int64, device=dev) if want_index else None
-    cand_count = torch.empty((B, L), dtype=torch.int32, device=dev)
+    cand_boxes, cand_scores, cand_labels, cand_index, cand_count = _candidate_outputs(dev, B, L, K, want_index,
+                                                                                      reuse_outputs)
     ws = _workspace(dev, "select", plan.ws_bytes)
     P, I64 = plan.P, plan.I64
     rc = _C.lib().od_select_candidates(
@@ -281,7 +308,7 @@ def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor]
 def select_candidates_planar(cls_maps: Sequence[Tensor], reg_maps: Sequence[Tensor], anchor_levels: Sequence[Tensor],
                              image_hw: Tensor, num_classes: int, score_thresh: float, topk: int, coder: int,
                              bbox_xform_clip: float, ctr_maps: Optional[Sequence[Tensor]] = None,
-                             want_index: bool = False):
+                             want_index: bool = False, reuse_outputs: bool = False):
     """select_candidates on the head's convolution outputs as they are: cls_maps[l] [B, A*C, H, W],
     reg_maps[l] [B, A*4, H, W], ctr_maps[l] [B, A, H, W] (FCOS); anchor_levels[l] [H*W*A, 4] in (y, x, a) order.
     Results are those of select_candidates on the permuted [B, H*W*A, .] tensors; the permute copy is not made."""
@@ -319,11 +346,8 @@ def select_candidates_planar(cls_maps: Sequence[Tensor], reg_maps: Sequence[Tens
         anc_t.append(a)
         anc_s.append(a.stride(0) if a.dim() == 3 else 0)
     K = int(topk)
-    cand_boxes = torch.empty((B, L * K, 4), dtype=torch.float32, device=dev)
-    cand_scores = torch.empty((B, L * K), dtype=torch.float32, device=dev)
-    cand_labels = torch.empty((B, L * K), dtype=torch.int32, device=dev)
-    cand_index = torch.empty((B, L * K), dtype=torch.int64, device=dev) if want_index else None
-    cand_count = torch.empty((B, L), dtype=torch.int32, device=dev)
+    cand_boxes, cand_scores, cand_labels, cand_index, cand_count = _candidate_outputs(dev, B, L, K, want_index,
+                                                                                      reuse_outputs)
     ws = _workspace(dev, "select", plan.ws_bytes)
     P, I64 = plan.P, plan.I64
     rc = _C.lib().od_select_candidates_planar(

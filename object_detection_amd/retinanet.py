@@ -181,10 +181,11 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
     K = int(topk_candidates)
     if planar_classes is not None:
         cb, cs, cl, _, cc = kernels.select_candidates_planar(cls_levels, reg_levels, shared, hw, planar_classes,
-                                                             score_thresh, K, coder, bbox_xform_clip, ctr_maps=ctr_levels)
+                                                             score_thresh, K, coder, bbox_xform_clip, ctr_maps=ctr_levels,
+                                                             reuse_outputs=True)
     else:
         cb, cs, cl, _, cc = kernels.select_candidates(cls_levels, reg_levels, shared, hw, score_thresh, K, coder,
-                                                      bbox_xform_clip, ctr_levels=ctr_levels)
+                                                      bbox_xform_clip, ctr_levels=ctr_levels, reuse_outputs=True)
     _, ob, os_, ol, oc = kernels.batched_nms_padded(cb, cs, cl, cc, K, True, nms_thresh, nms_mode,
                                                     int(detections_per_img), want_keep_idx=False)
     if box_scale is not None:
