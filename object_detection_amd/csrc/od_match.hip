@@ -18,13 +18,12 @@
 //
 // assign / heavy kernels: per-anchor max / argmax / thresholds -> `matched`, the raw argmax -> workspace,
 //   per-GT maximum over the wave's anchors (DPP max) -> global atomic max, and one 8-byte entry per
-//   (tile, GT with positive IoU): the GT, the tile's maximum, the first anchor attaining it and a flag
-//   telling whether other anchors of the tile tie with it.
+//   (tile, GT with positive IoU): the GT and the tile's maximum.
 // restore kernel (only with allow_low_quality_matches): torchvision restores anchor a to its own argmax
 //   when iou[g,a] equals the maximum of row g.  Such an anchor attains its tile's maximum, so the kernel
-//   only compares each entry's value with the global maximum of its GT and patches `matched` from the
-//   stored argmax.  For an entry flagged as a tie the wave recomputes that one
-//   (tile, GT) row segment with the same IoU code (hence bit-identical values) to find all tied anchors.
+//   compares each entry's value with the global maximum of its GT; for the few entries that match (the
+//   tiles that tie for a GT's maximum) a wave recomputes that (tile, GT) row segment with the same IoU code (hence
+//   bit-identical values) and patches `matched` from the stored argmax for every anchor attaining it.
 //   If some GT has maximum 0 (it overlaps no anchor) every anchor ties at 0 for that row and torchvision
 //   restores ALL anchors; a flag per image reproduces that.
 #include "od_common.h"
@@ -55,15 +54,13 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
                                  //                    index fits (halves this write stream), else int32
     int argmax16;
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
-    uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT << 9 | several << 8 | local anchor, y = value key
+    uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT, y = value key (tile maximum)
     int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
     unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
     int* any_flag;               // [1]                some image_flag is set
     int4* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot, GT met, -) for the cooperative kernel
-    uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = entry word, z = value key; image b owns the
+    uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT, z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
-    unsigned long long* wave_mask;   // [LCAP * batch * wtiles][R]  attaining-anchor masks of tie entries (same index as wave_list)
-    unsigned long long* heavy_mask;  // [heavy_cap][R]     same for heavy_entries
     long long list_stride;       // batch * wtiles
 };
 
@@ -157,50 +154,18 @@ __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const
     }
 }
 
-// IoU of the wave's anchors with one GT; updates (best, bidx).  With want_max it also returns the ordered
-// key `k` of the maximum over the wave's 256 anchors and, on the FIRST lane that holds an anchor attaining
-// it, the entry word  GT << 9 | several << 8 | local anchor  (0xffffffff on every other lane).  `several`
-// says that more than one anchor of the wave attains the maximum; then store_masks(m0, m1, m2, m3) is called
-// (wave-uniformly) with m_r = lanes whose anchor r attains it.
-template <typename S>
+// IoU of the wave's anchors with one GT; updates (best, bidx).  With want_max it also returns the ordered key of
+// the maximum over the wave's 256 anchors (kZeroKey: no anchor of the wave overlaps this GT), else 0.
 __device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1, float gy1, float gx2, float gy2,
-                                             float ga, float (&best)[R], int (&bidx)[R], bool want_max, uint32_t& k,
-                                             S store_masks) {
+                                             float ga, float (&best)[R], int (&bidx)[R], bool want_max) {
     float v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         v[r] = iou_pair(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
         if (v[r] > best[r]) { best[r] = v[r]; bidx[r] = g; }
     }
-    k = 0u;
-    if (!want_max) return 0xffffffffu;
-    const float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-    k = wave_umax_all(ordered_key(m));
-    if (k == kZeroKey) return 0xffffffffu;              // no anchor of the wave overlaps this GT
-    const bool mine = ordered_key(m) == k;
-    int first = -1, cnt = 0;
-#pragma unroll
-    for (int r = R - 1; r >= 0; --r)
-        if (v[r] == m) { first = r; ++cnt; }
-    const unsigned long long am = __ballot(mine);
-    const bool several = (am & (am - 1)) != 0 || __ballot(mine && cnt > 1) != 0;
-    if (several)
-        store_masks(__ballot(mine && v[0] == m), __ballot(mine && v[1] == m), __ballot(mine && v[2] == m),
-                    __ballot(mine && v[3] == m));
-    if (!mine || mbcnt(am) != 0) return 0xffffffffu;
-    return ((uint32_t)g << 9) | (several ? 256u : 0u) | (uint32_t)(first * 64 + (threadIdx.x & 63));
-}
-
-// lanes 0..3 store the four 64-bit attaining masks of a tie entry
-__device__ __forceinline__ void store_tie_masks(unsigned long long* dst, unsigned long long m0, unsigned long long m1,
-                                                unsigned long long m2, unsigned long long m3) {
-    static_assert(R == 4, "four masks per entry");
-    const int lane = threadIdx.x & 63;
-    uint32_t lo = (uint32_t)m0, hi = (uint32_t)(m0 >> 32);
-    if (lane == 1) { lo = (uint32_t)m1; hi = (uint32_t)(m1 >> 32); }
-    if (lane == 2) { lo = (uint32_t)m2; hi = (uint32_t)(m2 >> 32); }
-    if (lane == 3) { lo = (uint32_t)m3; hi = (uint32_t)(m3 >> 32); }
-    if (lane < R) reinterpret_cast<uint2*>(dst)[lane] = make_uint2(lo, hi);
+    if (!want_max) return 0u;
+    return wave_umax_all(ordered_key(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))));
 }
 
 __global__ __launch_bounds__(MT) void match_assign_kernel(
@@ -271,15 +236,10 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
     uint32_t kreg = 0u;                              // lane j: wave maximum of the IoU with GT g0 + j
 
     auto eval = [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
-        uint32_t k;
-        const long long slot = (long long)lcount * ws.list_stride + wslot;
-        const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
-                                      [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
-                                          store_tie_masks(ws.wave_mask + slot * R, a0, a1, a2, a3);
-                                      });
+        const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
         if (want_restore && k > kZeroKey) {            // wave-uniform: this GT overlaps an anchor of the wave
             kreg = (lane == j) ? k : kreg;
-            if (ent != 0xffffffffu) ws.wave_list[slot] = make_uint2(ent, k);
+            if (lane == 0) ws.wave_list[(long long)lcount * ws.list_stride + wslot] = make_uint2((uint32_t)g, k);
             ++lcount;                                  // <= HEAVY = LCAP for a light tile
         }
     };
@@ -371,18 +331,12 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
         uint32_t kreg = 0u;
         for_each_overlapping_gt(t, gt, m0, want_restore ? ws.gt_max_key : nullptr, 0, M, wave, NW,
             [&](int g, int j, int rank, float gx1, float gy1, float gx2, float gy2, float ga) {
-                uint32_t k;
-                const uint32_t ent = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0, k,
-                                              [&](unsigned long long a0, unsigned long long a1, unsigned long long a2, unsigned long long a3) {
-                                                  if (entries_fit) store_tie_masks(ws.heavy_mask + (ebase + rank) * R, a0, a1, a2, a3);
-                                              });
+                const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
                 if (want_restore) {
                     kreg = (lane == j) ? k : kreg;
                     // every survivor's slot is written: key 0 (never a maximum) marks "no overlapping anchor"
-                    if (entries_fit) {
-                        if (k == kZeroKey) { if (lane == 0) entries[rank] = make_uint4((uint32_t)wslot, 0u, 0u, 0u); }
-                        else if (ent != 0xffffffffu) entries[rank] = make_uint4((uint32_t)wslot, ent, k, 0u);
-                    }
+                    if (entries_fit && lane == 0)
+                        entries[rank] = make_uint4((uint32_t)wslot, (uint32_t)g, k == kZeroKey ? 0u : k, 0u);
                 }
             },
             [&](int g0, uint32_t cur) {
@@ -468,11 +422,64 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
     }
 }
 
+// Up to RB (tile, GT) row segments whose maximum equals the GT's global maximum: the wave recomputes their 256 IoUs
+// with the code of the assign kernels (bit-identical values) and restores every anchor that attains the maximum.
+// The loads of all RB segments are issued before the first IoU, so a wave with several hits (neighbouring tiles
+// often tie for the same GT) pays the memory latency once.  Wave-uniform arguments; wslot[q] < 0 = unused.
+#ifndef OD_RB
+#define OD_RB 4
+#endif
+constexpr int RB = OD_RB;
+__device__ __forceinline__ void restore_row_segments(const float4* __restrict__ anchors, long long anchor_batch_stride,
+                                                     long long n, int wtiles, const float4* __restrict__ gt,
+                                                     const int* __restrict__ gt_offsets, const MatchWs& ws,
+                                                     const int (&wslot)[RB], const int (&g)[RB], const uint32_t (&key)[RB],
+                                                     long long* __restrict__ matched) {
+    const int lane = threadIdx.x & 63;
+#ifdef OD_EXP_SKIP_RESTORE
+    return;
+#endif
+    float4 a[RB][R], gb[RB];
+    int am[RB][R];                                         // the anchors' argmax, requested with the boxes
+    long long first[RB];                                   // flat index of the segment's first anchor in `matched`
+    long long left[RB];                                    // anchors of the image from the segment's start
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        if (wslot[q] < 0) continue;
+        const int b = wslot[q] / wtiles, wt = wslot[q] - b * wtiles;
+        const long long base = (long long)wt * WTILE;
+        const float4* A = anchors + (long long)b * anchor_batch_stride;
+        gb[q] = gt[gt_offsets[b] + g[q]];
+        first[q] = (long long)b * n + base;
+        left[q] = n - base;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long idx = base + r * 64 + lane;
+            const long long ic = idx < n ? idx : n - 1;
+            a[q][r] = A[ic];
+            am[q][r] = get_argmax(ws, (long long)b * n + ic);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        if (wslot[q] < 0) continue;
+        const float ga = box_area(gb[q].x, gb[q].y, gb[q].z, gb[q].w);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float4 v4 = a[q][r];
+            const float v = iou_pair(gb[q].x, gb[q].y, gb[q].z, gb[q].w, ga, v4.x, v4.y, v4.z, v4.w,
+                                     box_area(v4.x, v4.y, v4.z, v4.w));
+            const long long off = r * 64 + lane;
+            if (off < left[q] && ordered_key(v) == key[q]) matched[first[q] + off] = (long long)am[q][r];
+        }
+    }
+}
+
 // Restore from the entries.  Blocks [0, light_blocks) take the light tiles, one thread per (entry slot,
-// tile); the remaining blocks take the heavy tiles' entries, one thread per entry.  An entry whose value
-// equals its GT's global maximum restores its anchor, or, if several anchors of the tile tie at that value,
-// every anchor in the entry's attaining masks.  Last, images whose flag is set restore every anchor.  If the heavy-entry buffer was too small (pathological inputs) the heavy blocks re-examine
-// every heavy tile against all GT of its image instead.
+// tile); the remaining blocks take the heavy tiles' entries, one thread per entry.  For an entry whose value
+// equals its GT's global maximum the wave re-examines that row segment (restore_row_segment).  Last, images
+// whose flag is set restore every anchor.  If the heavy-entry buffer was too small (pathological inputs) the
+// heavy blocks re-examine every heavy tile against all GT of its image instead.
 __global__ __launch_bounds__(256) void match_restore_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int batch,
     int light_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
@@ -497,8 +504,11 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
         limit = (overflow || hb / batch >= hblocks) ? 0 : (long long)(uint32_t)hc;
         ebase = entry_base(hb_image, m0);
     }
-    for (long long i0 = first; i0 < limit; i0 += nthreads) {
-        const long long i = i0 + lane;
+    // Heavy entries: consecutive entries belong to one tile and often hit together, so they are dealt to different
+    // waves (entry = lane * waves + wave); light entries are slot-major already.
+    const long long nwaves = nthreads >> 6, wave_id = first >> 6;
+    for (long long k0 = 0; k0 < limit; k0 += nthreads) {
+        const long long i = light ? k0 + first + lane : k0 + (long long)lane * nwaves + wave_id;
         uint32_t word = 0u, key = 0u;
         int wslot = 0;
         bool have = false;
@@ -515,31 +525,27 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
                 wslot = (int)ent.x; word = ent.y; key = ent.z; have = true;
             }
         }
-        if (have) {
-            const int b = wslot / wtiles, wt = wslot - b * wtiles;
-            const uint32_t gm = ws.gt_max_key[(long long)(gt_offsets[b] + (int)(word >> 9)) * GSTRIDE];
-            if (key == gm && !ws.image_flag[b]) {
-                long long* out = matched + (long long)b * n;
-                const long long abase = (long long)b * n;
-                const long long base = (long long)wt * WTILE;
-                if (word & 256u) {                       // several anchors of the tile tie: walk their masks
-                    const unsigned long long* mp = (light ? ws.wave_mask : ws.heavy_mask) + (ebase + i) * R;
-                    unsigned long long mask[R];
+        bool hit = false;
+        if (have && key > kZeroKey) {
+            const int b = wslot / wtiles;
+            hit = key == ws.gt_max_key[(long long)(gt_offsets[b] + (int)word) * GSTRIDE] && !ws.image_flag[b];
+        }
+        unsigned long long hits = __ballot(hit);         // the loop bounds are wave-uniform: all lanes are here
+        while (hits) {
+            int hs[RB], hg[RB];
+            uint32_t hk[RB];
 #pragma unroll
-                    for (int r = 0; r < R; ++r) mask[r] = mp[r];
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        while (mask[r]) {
-                            const long long idx = base + r * 64 + (__ffsll(mask[r]) - 1);
-                            mask[r] &= mask[r] - 1;
-                            if (idx < n) out[idx] = (long long)get_argmax(ws, abase + idx);
-                        }
-                    }
-                } else {
-                    const long long idx = base + (word & 255u);
-                    if (idx < n) out[idx] = (long long)get_argmax(ws, abase + idx);
+            for (int q = 0; q < RB; ++q) {
+                hs[q] = -1; hg[q] = 0; hk[q] = 0u;
+                if (hits) {
+                    const int src = __ffsll(hits) - 1;
+                    hits &= hits - 1;
+                    hs[q] = bcast_lane(wslot, src);
+                    hg[q] = bcast_lane((int)word, src);
+                    hk[q] = (uint32_t)bcast_lane((int)key, src);
                 }
             }
+            restore_row_segments(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, hs, hg, hk, matched);
         }
     }
     if (overflow && hb / batch < hblocks && !ws.image_flag[hb_image]) {   // one wave per (heavy tile, 64-GT chunk)
@@ -663,7 +669,7 @@ static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base
     return (size_t)HCAP_PER_GT * (size_t)(m_total > 0 ? m_total : 0) + 256 * (size_t)batch;
 }
 
-static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[11]) {
+static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[9]) {
     const size_t wtiles = (size_t)((n + WTILE - 1) / WTILE);
     const size_t tiles = (size_t)batch * wtiles;
     off[0] = 0;                                                                     // gt_max_key
@@ -674,16 +680,14 @@ static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t of
     off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // any_flag (256 B) + heavy_count
     off[6] = off[5] + 256 + (size_t)batch * 128;                                    // heavy_queue
     off[7] = off[6] + align256(tiles * sizeof(int4));                               // heavy_entries
-    off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));            // wave_mask
-    off[9] = off[8] + align256(tiles * LCAP * R * sizeof(unsigned long long));      // heavy_mask
-    off[10] = off[9] + align256(heavy_capacity(m_total, batch) * R * sizeof(unsigned long long));
+    off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));     // end
 }
 
 extern "C" size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch, int64_t n) {
     if (m_total < 0 || batch < 0 || n < 0) return 0;
-    size_t off[11];
+    size_t off[9];
     match_ws_layout(m_total, batch, n, off);
-    return off[10];
+    return off[8];
 }
 
 extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n,
@@ -699,7 +703,7 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     if (workspace_bytes < od_match_retinanet_workspace_bytes(m_total, batch, n)) return OD_ERR_WORKSPACE;
     if (!workspace || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    size_t off[11];
+    size_t off[9];
     match_ws_layout(m_total, batch, n, off);
     const int wtiles = (int)((n + WTILE - 1) / WTILE);
     const long long total_tiles = (long long)batch * wtiles;
@@ -716,21 +720,20 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     ws.heavy_count = (unsigned long long*)(w + off[5] + 256);
     ws.heavy_queue = (int4*)(w + off[6]);
     ws.heavy_entries = (uint4*)(w + off[7]);
-    ws.wave_mask = (unsigned long long*)(w + off[8]);
-    ws.heavy_mask = (unsigned long long*)(w + off[9]);
     ws.list_stride = total_tiles;
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
     dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
     if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total * GSTRIDE, s));
     OD_HIP(hipMemsetAsync(ws.any_flag, 0, 256 + (size_t)batch * 128, s));
-    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, (long
-                     long)anchor_batch_stride, (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore,
-                     high, low, (long long*)matched);
+    const long long stride = (long long)anchor_batch_stride;
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
+                     (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
+                     (long long*)matched);
     if (m_total > HEAVY) {
         int heavy_y = 4096 / batch > 64 ? 4096 / batch : 64;
         if (heavy_y > wtiles) heavy_y = wtiles;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_HEAVY, match_heavy_kernel, dim3((unsigned)batch, (unsigned)heavy_y),
-                         dim3(HT), 0, s, (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, wtiles,
+                         dim3(HT), 0, s, (const float4*)anchors, stride, (long long)n, wtiles,
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
@@ -739,10 +742,10 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
         const long long light_threads = total_tiles * LCAP;
         const int light_blocks = (int)((light_threads + 255) / 256 < 8192 ? (light_threads + 255) / 256 : 8192);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
-        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel, dim3((unsigned)(light_blocks +
-                         heavy_entry_blocks)), dim3(256), 0, s, (const float4*)anchors, (long
-                         long)anchor_batch_stride, (long long)n, wtiles, (int)batch, light_blocks, (const
-                         float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
+        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
+                         dim3((unsigned)(light_blocks + heavy_entry_blocks)), dim3(256), 0, s, (const float4*)anchors,
+                         stride, (long long)n, wtiles, (int)batch, light_blocks, (const float4*)gt_boxes, gt_offsets, ws,
+                         (long long*)matched);
     }
     return OD_OK;
 }
@@ -758,10 +761,10 @@ extern "C" int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, 
     if (n_first_level < 0 || n_last_level < 0 || n_first_level > n || n_last_level > n) return OD_ERR_ARG;
     if (batch > 65535) return OD_ERR_LIMIT;
     dim3 grid((unsigned)((n + FT - 1) / FT), (unsigned)batch);
-    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FCOS, match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream, (const
-                     float4*)anchors, (long long)anchor_batch_stride, (long long)n, (long long)n_first_level, (long
-                     long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius, (long
-                     long*)matched);
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FCOS, match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream,
+                     (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
+                     (long long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius,
+                     (long long*)matched);
     return OD_OK;
 }
 
