@@ -189,6 +189,27 @@ __device__ __forceinline__ float iou_pair(float gx1, float gy1, float gx2, float
     return inter / uni;
 }
 
+// The same with a wave-uniform first box (its coordinates sit in scalar registers, e.g. after v_readlane): the
+// scalar operand goes into the instruction directly instead of through a v_mov per coordinate and call.
+__device__ __forceinline__ float hw_min_su(float uniform, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float hw_max_su(float uniform, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "s"(uniform), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float iou_pair_uniform(float gx1, float gy1, float gx2, float gy2, float garea,
+                                                  float ax1, float ay1, float ax2, float ay2, float aarea) {
+    float w = fmaxf(hw_min_su(gx2, ax2) - hw_max_su(gx1, ax1), 0.0f);
+    float h = fmaxf(hw_min_su(gy2, ay2) - hw_max_su(gy1, ay1), 0.0f);
+    float inter = w * h;
+    float uni = (garea + aarea) - inter;
+    return inter / uni;
+}
+
 __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2) {
     return (x2 - x1) * (y2 - y1);
 }

@@ -161,7 +161,7 @@ __device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1
     float v[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        v[r] = iou_pair(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
+        v[r] = iou_pair_uniform(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
         if (v[r] > best[r]) { best[r] = v[r]; bidx[r] = g; }
     }
     if (!want_max) return 0u;
