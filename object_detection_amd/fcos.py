@@ -7,7 +7,7 @@ from __future__ import annotations
 import math
 from collections import OrderedDict
 from functools import partial
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import Tensor, nn

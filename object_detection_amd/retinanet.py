@@ -11,9 +11,7 @@ Convolutional head layers and the loss arithmetic downstream of matching are ord
 from __future__ import annotations
 
 import math
-import warnings
 from collections import OrderedDict
-from functools import partial
 from typing import Callable, Dict, List, Optional, Tuple
 
 import torch

@@ -15,7 +15,7 @@ from __future__ import annotations
 
 from collections import OrderedDict
 from functools import partial
-from typing import List, Optional, Union
+from typing import List, Optional
 
 import torch
 from torch import nn

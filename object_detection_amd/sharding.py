@@ -9,7 +9,7 @@ what replaces "run it on one device" when eight GPUs of a node are available.
 """
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 import torch
 import torch.distributed as dist

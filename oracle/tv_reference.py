@@ -25,7 +25,7 @@ non-stable ``sort`` in ``_batched_nms_vanilla``): descending score, then ascendi
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Sequence, Tuple
 
 import numpy as np
 import torch

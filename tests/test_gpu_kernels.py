@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from object_detection_amd import _C, kernels, synthetic
-from oracle import c_oracle, spec_math, tv_reference as tv
+from oracle import c_oracle, tv_reference as tv
 
 pytestmark = pytest.mark.gpu
 

@@ -115,7 +115,6 @@ def main():
             res[f"nms_thr{thr}_keep500"] = timed(lambda: kernels.batched_nms_padded(cb, cs, cl, cc, K, True, thr,
                                                                                    _C.NMS_AUTO_GPU, 500, want_keep_idx=False))
     if args.what in ("all", "loss"):
-        from object_detection_amd import det_utils
         head = synthetic.make_head_outputs(cfg, logits=args.logits)
         cls = head["cls_logits"].to(dev)
         targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)
