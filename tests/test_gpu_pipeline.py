@@ -273,6 +273,52 @@ def test_full_size_cfg2_two_images_and_batch_properties(device):
         assert int((m >= 0).sum()) >= 1
 
 
+def test_full_size_cfg4_selection_properties(device):
+    """One image of the largest configuration (1536 x 1536, 1 769 040 anchors, 91 classes, score threshold 0.05: 161 M
+    logits, about half of them above the threshold) -- too large for the CPU checker, so the candidate selection is
+    checked through properties that hold at any size, evaluated with torch on the GPU: per level the candidates are
+    sorted (score descending, flat index ascending on ties), their scores are the sigmoid of the logits they point
+    at (1e-6), there are min(K, #passing) of them, and no logit outside the selection scores higher than the last
+    one selected.  The detections are capped, sorted, inside the image and stable under a second NMS."""
+    cfg = dataclasses.replace(synthetic.CFG4, batch=1)
+    model = _model(cfg, device)
+    anchors = _anchors(model, cfg, device)
+    sizes = synthetic.level_sizes(cfg)
+    assert sum(sizes) == 1769040
+    g = torch.Generator(device=device).manual_seed(44)
+    hw = torch.tensor([[1536, 1536]], dtype=torch.int32, device=device)
+    K = cfg.topk_candidates
+    cls_l = [torch.randn((1, n, cfg.num_classes), generator=g, device=device) * 1.5 - 3.0 for n in sizes]
+    reg_l = [torch.randn((1, n, 4), generator=g, device=device) * 0.5 for n in sizes]
+    cb, cs, cl, ci, cc = kernels.select_candidates(cls_l, reg_l, anchors, hw, cfg.score_thresh, K, _C.CODER_BOXCODER,
+                                                   model.box_coder.bbox_xform_clip, want_index=True)
+    for lvl, logits in enumerate(cls_l):
+        flat = logits.reshape(-1)
+        n_pass = int((torch.sigmoid(flat) > cfg.score_thresh).sum())
+        count = int(cc[0, lvl])
+        assert abs(count - min(K, n_pass)) <= 2, (lvl, count, n_pass)       # torch's sigmoid may differ in the last bit at the threshold
+        sc = cs[0, lvl * K:lvl * K + count]
+        idx = ci[0, lvl * K:lvl * K + count]
+        assert int(idx.min()) >= 0 and int(idx.max()) < flat.numel() and idx.unique().numel() == count
+        assert bool((sc[:-1] >= sc[1:]).all())
+        ties = sc[:-1] == sc[1:]
+        assert bool((idx[:-1][ties] < idx[1:][ties]).all())
+        assert torch.allclose(sc, torch.sigmoid(flat[idx]), rtol=1e-6, atol=1e-7)
+        assert torch.equal(cl[0, lvl * K:lvl * K + count].long(), idx % cfg.num_classes)
+        if count == K:                                                        # nothing better was left out
+            rest = flat.clone()
+            rest[idx] = -float("inf")
+            assert float(torch.sigmoid(rest.max())) <= float(sc[-1]) * (1 + 1e-6)
+    split = {"cls_logits": cls_l, "bbox_regression": reg_l}
+    det = model.postprocess_detections(split, [anchors], [cfg.image_size])[0]
+    n = det["boxes"].shape[0]
+    assert 0 < n <= cfg.detections_per_img
+    assert bool((det["scores"][:-1] >= det["scores"][1:]).all()) and bool((det["scores"] > cfg.score_thresh).all())
+    assert bool((det["boxes"] >= 0).all()) and bool((det["boxes"] <= 1536).all())
+    again = box_ops.batched_nms(det["boxes"], det["scores"], det["labels"], cfg.nms_thresh, mode=_C.NMS_VANILLA)
+    assert again.numel() == n and torch.equal(again.cpu(), torch.arange(n))
+
+
 def test_concurrent_streams_do_not_share_scratch(device):
     """Steps enqueued on different HIP streams may overlap on the GPU; every stream has its own scratch buffers,
     so the results must equal those of the same calls made one after the other."""
