@@ -319,6 +319,44 @@ def test_full_size_cfg4_selection_properties(device):
     assert again.numel() == n and torch.equal(again.cpu(), torch.arange(n))
 
 
+def test_full_size_cfg5_dense_matching(device):
+    """The dense-target configuration at full size (786 240 anchors x 2000 GT per image, 1.57 G pairs): too large for
+    the CPU checkers inside a test, so two images are checked bit for bit against the checker's own formulas
+    (tv.box_iou, Matcher rules) evaluated chunk by chunk with torch on the GPU -- separate fp32 torch kernels round
+    exactly like the CPU ops -- and every image through invariants."""
+    cfg = dataclasses.replace(synthetic.CFG5, batch=4)
+    model = _model(cfg, device)
+    flat = torch.cat(_anchors(model, cfg, device))
+    targets = synthetic.make_targets(cfg, empty_image=3)
+    gts = [t["boxes"].to(device) for t in targets]
+    assert gts[0].shape[0] == 2000 and flat.shape[0] == 786240
+    matched = kernels.match_retinanet(flat, gts, cfg.fg_iou_thresh, cfg.bg_iou_thresh, True)
+    n = flat.shape[0]
+    for i in (0, 2):
+        gt = gts[i]
+        vals = torch.full((n,), -1.0, device=device)
+        arg = torch.zeros((n,), dtype=torch.int64, device=device)
+        gmax = torch.empty((gt.shape[0],), device=device)
+        for g0 in range(0, gt.shape[0], 50):
+            iou = tv.box_iou(gt[g0:g0 + 50], flat)                      # [50, N]
+            v, a = iou.max(dim=0)                                       # first maximal index inside the chunk
+            better = v > vals                                           # strict: earlier chunks win ties
+            arg = torch.where(better, a + g0, arg)
+            vals = torch.where(better, v, vals)
+            gmax[g0:g0 + 50] = iou.max(dim=1)[0]
+        want = arg.clone()
+        want[vals < cfg.bg_iou_thresh] = -1
+        want[(vals >= cfg.bg_iou_thresh) & (vals < cfg.fg_iou_thresh)] = -2
+        restore = torch.zeros((n,), dtype=torch.bool, device=device)
+        for g0 in range(0, gt.shape[0], 50):
+            restore |= (tv.box_iou(gt[g0:g0 + 50], flat) == gmax[g0:g0 + 50, None]).any(dim=0)
+        want[restore] = arg[restore]
+        assert torch.equal(matched[i], want), (i, int((matched[i] != want).sum()))
+    assert bool((matched[3] == -1).all())
+    for i in range(3):
+        assert int(matched[i].max()) < 2000 and int(matched[i].min()) >= -2 and int((matched[i] >= 0).sum()) > 0
+
+
 def test_concurrent_streams_do_not_share_scratch(device):
     """Steps enqueued on different HIP streams may overlap on the GPU; every stream has its own scratch buffers,
     so the results must equal those of the same calls made one after the other."""
