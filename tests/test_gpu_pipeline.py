@@ -137,6 +137,31 @@ def test_fcos_postprocess_and_match(device):
         assert torch.equal(g.cpu(), w)
 
 
+def test_fcos_full_size_cfg3(device):
+    """The FCOS configuration as specified (16 images, 1024 x 1024, 21 824 locations, 200 GT each): centre-sampling
+    matches and detections of every image against the CPU checker, bit for bit."""
+    cfg = synthetic.CFG3
+    model = _model(cfg, device, arch="fcos")
+    anchors = _anchors(model, cfg, device)
+    sizes = synthetic.level_sizes(cfg)
+    assert sum(sizes) == 21824
+    head = synthetic.make_head_outputs(cfg, with_ctrness=True)
+    head["bbox_regression"] = head["bbox_regression"].abs()
+    shapes = [cfg.image_size] * cfg.batch
+    split_d = {k: [t.to(device) for t in v.split(sizes, dim=1)] for k, v in head.items()}
+    split_c = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+    dets = model.postprocess_detections(split_d, [anchors] * cfg.batch, shapes)
+    ref = tv.fcos_postprocess(split_c, [[a.cpu() for a in anchors]] * cfg.batch, shapes, cfg.score_thresh,
+                              cfg.topk_candidates, cfg.nms_thresh, cfg.detections_per_img, math="spec", device_rule="gpu")
+    _assert_dets_equal(dets, ref)
+    targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)
+    flat = torch.cat(anchors)
+    got = model.match_anchors([{k: v.to(device) for k, v in t.items()} for t in targets], [flat] * cfg.batch, sizes)
+    want = tv.fcos_match([t["boxes"] for t in targets], [flat.cpu()] * cfg.batch, sizes, 1.5)
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+
+
 def test_forward_end_to_end_shapes(device):
     """model(images) / model(images, targets) through transform, stub backbone, head and the kernels."""
     torch.manual_seed(0)
