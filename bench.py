@@ -296,7 +296,7 @@ def main():
             p["algorithmic_MB"] = b / 1e6
             p["GBps"] = b / (p["ms_per_launch"] * 1e-3) / 1e9 if p["ms_per_launch"] > 0 else 0.0
         result = {
-            "metric": "images/sec (match+decode+NMS) at 1024^2 bs16",
+            "metric": "images/sec (match+decode+NMS) at 1024\u00b2 bs16",
             "value": images / elapsed,
             "unit": "images/s",
             "n_gpus": world,
