@@ -165,7 +165,10 @@ __device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1
         if (v[r] > best[r]) { best[r] = v[r]; bidx[r] = g; }
     }
     if (!want_max) return 0u;
-    return wave_umax_all(ordered_key(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]))));
+    float m = v[0];
+#pragma unroll
+    for (int r = 1; r < R; ++r) m = fmaxf(m, v[r]);
+    return wave_umax_all(ordered_key(m));
 }
 
 __global__ __launch_bounds__(MT) void match_assign_kernel(
@@ -426,10 +429,7 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
 // with the code of the assign kernels (bit-identical values) and restores every anchor that attains the maximum.
 // The loads of all RB segments are issued before the first IoU, so a wave with several hits (neighbouring tiles
 // often tie for the same GT) pays the memory latency once.  Wave-uniform arguments; wslot[q] < 0 = unused.
-#ifndef OD_RB
-#define OD_RB 4
-#endif
-constexpr int RB = OD_RB;
+constexpr int RB = 4;
 __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ anchors, long long anchor_batch_stride,
                                                      long long n, int wtiles, const float4* __restrict__ gt,
                                                      const int* __restrict__ gt_offsets, const MatchWs& ws,
