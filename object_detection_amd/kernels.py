@@ -58,24 +58,26 @@ def _f32c(t: Tensor) -> Tensor:
 
 def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32) -> Tensor:
     """Small host tuple -> device tensor, cached by value (avoids a host->device copy per call)."""
-    key = (device.index, dtype, tuple(int(v) for v in values))
+    key = (device.index, _raw_stream(device), dtype, tuple(int(v) for v in values))     # per stream: the upload is asynchronous
     t = _small_cache.get(key)
     if t is None:
         if len(_small_cache) > 4096:
             _small_cache.clear()
-        t = torch.tensor(list(key[2]), dtype=dtype, device=device)
+        # through pinned memory and an asynchronous copy: a copy from pageable memory would make the host wait for
+        # everything queued on the stream (per step, when the GT counts change every step)
+        t = torch.tensor(list(key[3]), dtype=dtype).pin_memory().to(device, non_blocking=True)
         _small_cache[key] = t
     return t
 
 
 def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
     """Small host tuple of floats -> fp32 device tensor, cached by value."""
-    key = (device.index, "f32", tuple(float(v) for v in values))
+    key = (device.index, _raw_stream(device), "f32", tuple(float(v) for v in values))
     t = _small_cache.get(key)
     if t is None:
         if len(_small_cache) > 4096:
             _small_cache.clear()
-        t = torch.tensor(list(key[2]), dtype=torch.float32, device=device)
+        t = torch.tensor(list(key[3]), dtype=torch.float32).pin_memory().to(device, non_blocking=True)
         _small_cache[key] = t
     return t
 
