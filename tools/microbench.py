@@ -146,6 +146,45 @@ def main():
         E = cls.numel()
         res["loss_GBps"] = {"focal_fwd": (4 * E + 8 * matched.numel()) / (res["loss"]["focal_fwd"] * 1e-6) / 1e9,
                             "focal_bwd": (8 * E + 8 * matched.numel()) / (res["loss"]["focal_bwd"] * 1e-6) / 1e9}
+    if args.what in ("all", "train"):
+        # training side of the model: compute_loss forward + backward for the batch, fused kernels against the same
+        # steps as torch ops on the GPU (per-image loop, as torchvision writes it)
+        import time
+        from object_detection_amd import det_utils
+        from object_detection_amd.retinanet_model import get_model
+        L = len(cfg.grids)
+        model = get_model(cfg.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
+                          fg_iou_thresh=cfg.fg_iou_thresh, bg_iou_thresh=cfg.bg_iou_thresh).to(dev)
+        head = {k: v.to(dev).requires_grad_(True) for k, v in synthetic.make_head_outputs(cfg, logits=args.logits).items()}
+        targets = [{k: v.to(dev) for k, v in t.items()} for t in synthetic.make_targets(cfg, empty_image=cfg.batch - 1)]
+        apl = [anchors] * cfg.batch
+
+        def fused_step():
+            losses = model.compute_loss(targets, head, apl)
+            (losses["classification"] + losses["bbox_regression"]).backward()
+
+        def torch_step():
+            matched = model.match_anchors(targets, apl)
+            cls_losses, reg_losses = [], []
+            for t, logits, reg, m in zip(targets, head["cls_logits"], head["bbox_regression"], matched):
+                fg = m >= 0
+                tgt = torch.zeros_like(logits)
+                tgt[fg, t["labels"][m[fg]]] = 1.0
+                valid = m != -2
+                cls_losses.append(det_utils.sigmoid_focal_loss(logits[valid], tgt[valid], reduction="sum") / max(1, int(fg.sum())))
+                fi = torch.where(fg)[0]
+                reg_losses.append(det_utils._box_loss("giou", model.head.regression_head.box_coder, anchors[fi],
+                                                      t["boxes"][m[fi]], reg[fi]) / max(1, fi.numel()))
+            (sum(cls_losses) / cfg.batch + sum(reg_losses) / cfg.batch).backward()
+
+        for name, fn, reps in (("fused", fused_step, 20), ("torch_ops_after_fused_matching", torch_step, 3)):
+            fn()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            res["train_step_us_" + name] = round((time.perf_counter() - t0) / reps * 1e6, 1)
     if args.what in ("all", "pre"):
         from object_detection_amd.transform import GeneralizedRCNNTransform
         tr = GeneralizedRCNNTransform(1024, 1024, [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
