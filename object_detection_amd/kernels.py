@@ -26,6 +26,8 @@ def _require_gpu(t: Tensor, name: str) -> None:
 
 def _raw_stream(device: torch.device) -> int:
     """Handle of the current HIP stream of ``device`` (the integer torch keeps; no Stream object is built)."""
+    if device.type != "cuda":
+        raise RuntimeError(f"inputs must be GPU tensors: object_detection_amd has no CPU code path (got device {device})")
     return torch._C._cuda_getCurrentRawStream(device.index if device.index is not None else torch.cuda.current_device())
 
 

@@ -68,6 +68,44 @@ def test_argument_errors_without_gpu():
         _C.check(-3, "x")
 
 
+def test_argument_errors_of_loss_transform_and_planar_entries():
+    """The entry points added for the head losses, the input transform and the channel-major selection reject bad
+    arguments before anything is launched (no GPU needed)."""
+    lib = _C.lib()
+    null, p16, p256 = ctypes.c_void_p(0), ctypes.c_void_p(16), ctypes.c_void_p(256)
+    assert lib.od_focal_loss_workspace_bytes(786240, 4, 16) >= 16 * 768 * 12
+    assert lib.od_focal_loss_workspace_bytes(-1, 4, 16) == 0
+    # unknown element type, null logits, workspace too small
+    assert lib.od_focal_loss_forward(p16, 7, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 1 << 20, null) == -1
+    assert lib.od_focal_loss_forward(null, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 1 << 20, null) == -1
+    assert lib.od_focal_loss_forward(p16, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 8, null) == -3
+    assert lib.od_focal_loss_backward(p16, 1, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, null, p16, p16, null) == -1
+    w = (ctypes.c_float * 4)(1.0, 1.0, 1.0, 1.0)
+    zero_w = (ctypes.c_float * 4)(1.0, 0.0, 1.0, 1.0)
+    assert lib.od_box_loss_workspace_bytes(1000, 2) > 0
+    assert lib.od_box_loss_forward(p16, 0, 40, p16, 0, 10, p16, p16, p16, 1, 9, 1.0, w, 4.135, 1e-7, p16, p16, p16, p256,
+                                   1 << 20, null) == -1                               # unknown loss type
+    assert lib.od_box_loss_forward(p16, 0, 40, p16, 0, 10, p16, p16, p16, 1, 2, 1.0, zero_w, 4.135, 1e-7, p16, p16, p16,
+                                   p256, 1 << 20, null) == -1                         # a zero coder weight
+    assert lib.od_box_loss_forward(ctypes.c_void_p(20), 0, 40, p16, 0, 10, p16, p16, p16, 1, 2, 1.0, w, 4.135, 1e-7, p16,
+                                   p16, p16, p256, 1 << 20, null) == -1               # rows not aligned to four elements
+    imgs = (ctypes.c_void_p * 1)(16)
+    one = (ctypes.c_int32 * 1)(8)
+    big = (ctypes.c_int32 * 1)(64)
+    f3 = (ctypes.c_float * 5)(0.5, 0.5, 0.5, 0.5, 0.5)
+    assert lib.od_preprocess_images(imgs, one, one, one, one, 1, 5, f3, f3, p16, 32, 32, null) == -1    # > 4 channels
+    assert lib.od_preprocess_images(imgs, one, one, big, one, 1, 3, f3, f3, p16, 32, 32, null) == -1    # resized > batch
+    assert lib.od_preprocess_images(imgs, one, one, one, one, 0, 3, f3, f3, p16, 32, 32, null) == 0     # empty batch
+    sizes = (ctypes.c_int64 * 1)(90)
+    ptrs = (ctypes.c_void_p * 1)(16)
+    strides = (ctypes.c_int64 * 1)(360)
+    args = (ptrs, strides, None, None, ptrs, strides, ptrs, (ctypes.c_int64 * 1)(0), sizes)
+    tail = (1, 1, 4, p16, 0.5, 10, 0, 4.135, p16, p16, p16, null, p16, p256, 1 << 20, null)
+    assert lib.od_select_candidates_planar(*args, None, *tail) == -1                  # plane sizes missing
+    assert lib.od_select_candidates_planar(*args, (ctypes.c_int64 * 1)(7), *tail) == -1   # 90 anchors are not a multiple of 7
+    assert lib.od_profile_stride(0) == -1 and lib.od_profile_stride(1) == 0
+
+
 def test_no_cpu_fallback():
     from object_detection_amd import boxes, kernels
     with pytest.raises(RuntimeError, match="GPU tensor"):
