@@ -54,12 +54,12 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
                                  //                    index fits (halves this write stream), else int32
     int argmax16;
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
-    uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT, y = value key (tile maximum)
+    uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT (index into the batch's GT list), y = value key (tile maximum)
     int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
     unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
     int* any_flag;               // [1]                some image_flag is set
     int4* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot, GT met, -) for the cooperative kernel
-    uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT, z = value key; image b owns the
+    uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT (as above), z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
     long long list_stride;       // batch * wtiles
 };
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
         if (want_restore && k > kZeroKey) {            // wave-uniform: this GT overlaps an anchor of the wave
             kreg = (lane == j) ? k : kreg;
-            if (lane == 0) ws.wave_list[(long long)lcount * ws.list_stride + wslot] = make_uint2((uint32_t)g, k);
+            if (lane == 0) ws.wave_list[(long long)lcount * ws.list_stride + wslot] = make_uint2((uint32_t)(m0 + g), k);
             ++lcount;                                  // <= HEAVY = LCAP for a light tile
         }
     };
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
                     kreg = (lane == j) ? k : kreg;
                     // every survivor's slot is written: key 0 (never a maximum) marks "no overlapping anchor"
                     if (entries_fit && lane == 0)
-                        entries[rank] = make_uint4((uint32_t)wslot, (uint32_t)g, k == kZeroKey ? 0u : k, 0u);
+                        entries[rank] = make_uint4((uint32_t)wslot, (uint32_t)(m0 + g), k == kZeroKey ? 0u : k, 0u);
                 }
             },
             [&](int g0, uint32_t cur) {
@@ -436,9 +436,6 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
                                                      const int (&wslot)[RB], const int (&g)[RB], const uint32_t (&key)[RB],
                                                      long long* __restrict__ matched) {
     const int lane = threadIdx.x & 63;
-#ifdef OD_EXP_SKIP_RESTORE
-    return;
-#endif
     float4 a[RB][R], gb[RB];
     int am[RB][R];                                         // the anchors' argmax, requested with the boxes
     long long first[RB];                                   // flat index of the segment's first anchor in `matched`
@@ -449,7 +446,11 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
         const int b = wslot[q] / wtiles, wt = wslot[q] - b * wtiles;
         const long long base = (long long)wt * WTILE;
         const float4* A = anchors + (long long)b * anchor_batch_stride;
-        gb[q] = gt[gt_offsets[b] + g[q]];
+        // g[q] indexes the batch's GT list; a vector load, so that the wave does not stop for a scalar one before
+        // the anchor loads of the next segment are issued
+        int gi = g[q];
+        asm volatile("" : "+v"(gi));
+        gb[q] = gt[gi];
         first[q] = (long long)b * n + base;
         left[q] = n - base;
 #pragma unroll
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
         bool hit = false;
         if (have && key > kZeroKey) {
             const int b = wslot / wtiles;
-            hit = key == ws.gt_max_key[(long long)(gt_offsets[b] + (int)word) * GSTRIDE] && !ws.image_flag[b];
+            hit = key == ws.gt_max_key[(long long)word * GSTRIDE] && !ws.image_flag[b];
         }
         unsigned long long hits = __ballot(hit);         // the loop bounds are wave-uniform: all lanes are here
         while (hits) {
