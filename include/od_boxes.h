@@ -190,20 +190,25 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
  *   forward  -> loss fp32 [1] (mean over images), per_image_loss fp32 [batch], num_foreground int32 [batch]
  *   backward -> grad_logits [batch, n, num_classes] of the same element type (contiguous; 16-bit values rounded once,
  *               to nearest even) = grad_loss[0] * d loss / d cls_logits, from the forward's num_foreground
+ * normalization: OD_LOSS_NORM_PER_IMAGE as above; OD_LOSS_NORM_BATCH is the FCOS classification loss
+ *   (torchvision FCOSHead.compute_loss: sigmoid_focal_loss over the whole batch, "sum", / max(1, #foreground of the
+ *   batch); FCOS built at reference retinanet_model.py:56-60); num_foreground[b] then holds the batch total.
  * Floating point: agrees with the fp32 torch evaluation to about 1e-6 relative (tests use 1e-5).
  */
+#define OD_LOSS_NORM_PER_IMAGE 0 /* mean over images of sum_b / max(1, #fg_b)   (RetinaNet heads) */
+#define OD_LOSS_NORM_BATCH 1     /* sum over the batch / max(1, #fg of the batch) (FCOS head)       */
 #define OD_DTYPE_F32 0
 #define OD_DTYPE_F16 1          /* IEEE half    */
 #define OD_DTYPE_BF16 2         /* bfloat16     */
 size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, int32_t batch);
 int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                           const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
-                          float alpha, float gamma, float* loss, float* per_image_loss, int32_t* num_foreground,
-                          void* workspace, size_t workspace_bytes, void* stream);
+                          float alpha, float gamma, int32_t normalization, float* loss, float* per_image_loss,
+                          int32_t* num_foreground, void* workspace, size_t workspace_bytes, void* stream);
 int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                            const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, int32_t batch,
-                           float alpha, float gamma, const int32_t* num_foreground, const float* grad_loss,
-                           void* grad_logits, void* stream);
+                           float alpha, float gamma, int32_t normalization, const int32_t* num_foreground,
+                           const float* grad_loss, void* grad_logits, void* stream);
 
 /*
  * Regression loss of the RetinaNet head.  Replaces torchvision RetinaNetRegressionHead.compute_loss =
@@ -234,6 +239,30 @@ int od_box_loss_backward(const void* bbox_regression, int32_t dtype, int64_t bat
                          const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta, const float* weights,
                          float bbox_xform_clip, float eps, const int32_t* num_foreground, const float* grad_loss,
                          void* grad_regression, void* stream);
+
+/*
+ * Regression and centre-ness losses of the FCOS head.  Replaces, in torchvision FCOSHead.compute_loss (FCOS built at
+ * reference retinanet_model.py:56-60), generalized_box_iou_loss(BoxLinearCoder.decode(bbox_regression, anchors)[fg],
+ * gt[fg], "sum") and binary_cross_entropy_with_logits(bbox_ctrness[fg], ctrness_target[fg], "sum"), both divided by
+ * max(1, #foreground of the batch); ctrness_target = sqrt(min(l,r)/max(l,r) * min(t,b)/max(t,b)) of
+ * BoxLinearCoder.encode(anchors, gt).  fg = matched >= 0.
+ *   bbox_regression [batch, n, 4], bbox_ctrness [batch, n] of element type dtype; matched int64 [batch, n]
+ *   forward  -> loss_regression, loss_ctrness fp32 [1]; num_foreground int32 [batch] (the batch total, repeated)
+ *   backward -> grad_regression [batch, n, 4], grad_ctrness [batch, n] (contiguous, same element type)
+ *   workspace: od_box_loss_workspace_bytes(n, batch)
+ */
+int od_fcos_box_loss_forward(const void* bbox_regression, const void* bbox_ctrness, int32_t dtype,
+                             int64_t reg_batch_stride, int64_t ctr_batch_stride, const float* anchors,
+                             int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                             const int32_t* gt_offsets, int32_t batch, float eps, float* loss_regression,
+                             float* loss_ctrness, int32_t* num_foreground, void* workspace, size_t workspace_bytes,
+                             void* stream);
+int od_fcos_box_loss_backward(const void* bbox_regression, const void* bbox_ctrness, int32_t dtype,
+                              int64_t reg_batch_stride, int64_t ctr_batch_stride, const float* anchors,
+                              int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
+                              const int32_t* gt_offsets, int32_t batch, float eps, const int32_t* num_foreground,
+                              const float* grad_loss_regression, const float* grad_loss_ctrness, void* grad_regression,
+                              void* grad_ctrness, void* stream);
 
 /*
  * Image side of the model's input transform in one pass.  Replaces torchvision GeneralizedRCNNTransform.forward's

@@ -50,9 +50,13 @@ SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "od_focal_loss_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "od_focal_loss_forward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,
-                                        _P, _P, _P, _P, c_size_t, _P]),
+                                        c_int32, _P, _P, _P, _P, c_size_t, _P]),
     "od_focal_loss_backward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,
-                                         _P, _P, _P, _P]),
+                                         c_int32, _P, _P, _P, _P]),
+    "od_fcos_box_loss_forward": (c_int32, [_P, _P, c_int32, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int32,
+                                           c_float, _P, _P, _P, _P, c_size_t, _P]),
+    "od_fcos_box_loss_backward": (c_int32, [_P, _P, c_int32, c_int64, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int32,
+                                            c_float, _P, _P, _P, _P, _P, _P]),
     "od_box_loss_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "od_box_loss_forward": (c_int32, [_P, c_int32, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int32, c_int32, c_float,
                                       _P, c_float, c_float, _P, _P, _P, _P, c_size_t, _P]),
@@ -69,6 +73,7 @@ KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_io
                 "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+LOSS_NORM_PER_IMAGE, LOSS_NORM_BATCH = 0, 1
 
 _lib = None
 

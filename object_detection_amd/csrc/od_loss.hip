@@ -110,6 +110,7 @@ struct LossArgs {
     const int* gt_offsets;              // [batch + 1]
     float alpha, gamma;
     int blocks_per_image;
+    int norm;                           // OD_LOSS_NORM_*
 };
 
 // anchor and class of flat element e (one division per group of four elements; 32-bit when E < 2^32)
@@ -280,16 +281,21 @@ __global__ __launch_bounds__(LT) void focal_forward_kernel(LossArgs p, double* _
     }
 }
 
-// one workgroup: per-image totals, loss_b / max(1, #fg_b), and their mean
+// one workgroup: per-image totals and the loss.
+//   norm = OD_LOSS_NORM_PER_IMAGE: loss = mean_b( sum_b / max(1, #fg_b) )            (RetinaNet heads)
+//   norm = OD_LOSS_NORM_BATCH    : loss = sum_b sum_b / max(1, sum_b #fg_b)          (FCOS head); num_fg[b] then holds
+//                                  the batch total for every b, which is what the backward kernels divide by
+// per_image may be null.
 __global__ __launch_bounds__(1024) void focal_finalize_kernel(const double* __restrict__ part_loss,
                                                               const int* __restrict__ part_fg, int blocks_per_image,
-                                                              int batch, float* __restrict__ loss_out,
+                                                              int batch, int norm, float* __restrict__ loss_out,
                                                               float* __restrict__ per_image, int* __restrict__ num_fg) {
     __shared__ double s_d[1024 / 64];
     __shared__ int s_i[1024 / 64];
     __shared__ double s_total;
+    __shared__ long long s_fg_total;
     const int tid = threadIdx.x;
-    if (tid == 0) s_total = 0.0;
+    if (tid == 0) { s_total = 0.0; s_fg_total = 0; }
     for (int b = 0; b < batch; ++b) {
         double t = 0.0;
         int f = 0;
@@ -306,14 +312,30 @@ __global__ __launch_bounds__(1024) void focal_finalize_kernel(const double* __re
             double tt = 0.0;
             int ff = 0;
             for (int w = 0; w < 1024 / 64; ++w) { tt += s_d[w]; ff += s_i[w]; }
-            const double lb = tt / (double)(ff > 1 ? ff : 1);
-            per_image[b] = (float)lb;
-            num_fg[b] = ff;
-            s_total += lb;
+            if (norm == OD_LOSS_NORM_PER_IMAGE) {
+                const double lb = tt / (double)(ff > 1 ? ff : 1);
+                if (per_image) per_image[b] = (float)lb;
+                num_fg[b] = ff;
+                s_total += lb;
+            } else {
+                if (per_image) per_image[b] = (float)tt;         // divided by the batch's count below
+                s_total += tt;
+                s_fg_total += ff;
+            }
         }
     }
     __syncthreads();
-    if (tid == 0) *loss_out = (float)(s_total / (double)batch);
+    if (norm == OD_LOSS_NORM_PER_IMAGE) {
+        if (tid == 0) *loss_out = (float)(s_total / (double)batch);
+        return;
+    }
+    const long long ft = s_fg_total;
+    const double denom = (double)(ft > 1 ? ft : 1);
+    for (int b = tid; b < batch; b += 1024) {
+        if (per_image) per_image[b] = (float)((double)per_image[b] / denom);
+        num_fg[b] = (int)(ft < 0x7fffffff ? ft : 0x7fffffff);
+    }
+    if (tid == 0) *loss_out = (float)(s_total / denom);
 }
 
 template <bool G2, typename T>
@@ -330,7 +352,7 @@ __global__ __launch_bounds__(LT) void focal_backward_kernel(LossArgs p, const in
     const bool vec_ok = ((((uintptr_t)(src + e0)) & vec_mask<T>()) == 0) &&
                         ((((uintptr_t)(dst + e0)) & vec_mask<T>()) == 0) && (e0 + LCHUNK <= E);
     const int nf = num_fg[b];
-    const float scale = *grad_out / ((float)(nf > 1 ? nf : 1) * (float)batch);
+    const float scale = *grad_out / ((float)(nf > 1 ? nf : 1) * (p.norm == OD_LOSS_NORM_PER_IMAGE ? (float)batch : 1.0f));
     float gr[LPT / 4][4];
     if (vec_ok && p.num_classes >= 4) {
         for_each_element_fast(p, b, src, e0, small, [&](int it, int k, float x, bool t, bool valid) {
@@ -379,8 +401,9 @@ size_t elem_size(int32_t dtype) {        // 0 for an unknown element type
 
 int fill_args(LossArgs* a, const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
               const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets, float alpha, float gamma,
-              int blocks) {
+              int32_t normalization, int blocks) {
     if (!cls_logits || !matched || !gt_offsets || elem_size(dtype) == 0) return OD_ERR_ARG;
+    if (normalization != OD_LOSS_NORM_PER_IMAGE && normalization != OD_LOSS_NORM_BATCH) return OD_ERR_ARG;
     if (batch_stride < n * (long long)num_classes) return OD_ERR_ARG;
     if (((uintptr_t)cls_logits & (elem_size(dtype) - 1)) || ((uintptr_t)matched & 7)) return OD_ERR_ARG;
     a->logits = cls_logits;
@@ -393,6 +416,7 @@ int fill_args(LossArgs* a, const void* cls_logits, int32_t dtype, int64_t batch_
     a->alpha = alpha;
     a->gamma = gamma;
     a->blocks_per_image = blocks;
+    a->norm = normalization;
     return OD_OK;
 }
 
@@ -422,27 +446,38 @@ struct BoxLossArgs {
     int loss_type;
     float beta, wx, wy, ww, wh, clip, eps;
     int blocks_per_image;
+    int coder;                          // OD_CODER_BOXCODER, or OD_CODER_LINEAR (FCOS; "giou" only)
+    int norm;                           // OD_LOSS_NORM_*
+    const void* ctr;                    // FCOS centre-ness logits [batch, n] of the element type, or null
+    long long ctr_stride;
 };
 
 struct BoxTerms {
     float loss;
     float4 grad;                        // d loss / d regression
+    float ctr_loss, ctr_grad;           // centre-ness: BCE-with-logits against the encoded target, and d / d logit
 };
 
 // derivative of max(a, b) (sel = a > b) or min(a, b) (sel = a < b) with respect to a, torch's tie rule (one half)
 __device__ __forceinline__ float pick(bool sel, float a, float b) { return sel ? 1.0f : (a == b ? 0.5f : 0.0f); }
 
 __device__ __forceinline__ BoxTerms giou_terms(const BoxLossArgs& p, float4 r, float4 a, float4 g) {
-    // BoxCoder.decode_single
     const float w = a.z - a.x, h = a.w - a.y;
-    const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
-    const float dx = r.x / p.wx, dy = r.y / p.wy;
-    const float dw0 = r.z / p.ww, dh0 = r.w / p.wh;
-    const float dw = fminf(dw0, p.clip), dh = fminf(dh0, p.clip);
-    const float pcx = dx * w + cx, pcy = dy * h + cy;
-    const float pw = expf(dw) * w, ph = expf(dh) * h;
-    const float hw = 0.5f * pw, hh = 0.5f * ph;
-    const float x1 = pcx - hw, y1 = pcy - hh, x2 = pcx + hw, y2 = pcy + hh;
+    float x1, y1, x2, y2;
+    float dw0 = 0.0f, dh0 = 0.0f, pw = 0.0f, ph = 0.0f;
+    if (p.coder == OD_CODER_BOXCODER) {                 // BoxCoder.decode_single
+        const float cx = a.x + 0.5f * w, cy = a.y + 0.5f * h;
+        const float dx = r.x / p.wx, dy = r.y / p.wy;
+        dw0 = r.z / p.ww; dh0 = r.w / p.wh;
+        const float dw = fminf(dw0, p.clip), dh = fminf(dh0, p.clip);
+        const float pcx = dx * w + cx, pcy = dy * h + cy;
+        pw = expf(dw) * w; ph = expf(dh) * h;
+        const float hw = 0.5f * pw, hh = 0.5f * ph;
+        x1 = pcx - hw; y1 = pcy - hh; x2 = pcx + hw; y2 = pcy + hh;
+    } else {                                            // BoxLinearCoder(normalize_by_size=True).decode
+        const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w);
+        x1 = cx - r.x * w; y1 = cy - r.y * h; x2 = cx + r.z * w; y2 = cy + r.w * h;
+    }
     // generalized_box_iou_loss
     const float ix1 = fmaxf(x1, g.x), iy1 = fmaxf(y1, g.y), ix2 = fminf(x2, g.z), iy2 = fminf(y2, g.w);
     const bool hit = (iy2 > iy1) && (ix2 > ix1);
@@ -472,12 +507,30 @@ __device__ __forceinline__ BoxTerms giou_terms(const BoxLossArgs& p, float4 r, f
         gx2 += dI * ih * pick(x2 < g.z, x2, g.z);
         gy2 += dI * iw * pick(y2 < g.w, y2, g.w);
     }
-    // through decode_single; clamp passes the gradient where the value is not above the bound
-    t.grad.x = (gx1 + gx2) * w / p.wx;
-    t.grad.y = (gy1 + gy2) * h / p.wy;
-    t.grad.z = (dw0 <= p.clip) ? 0.5f * (gx2 - gx1) * pw / p.ww : 0.0f;
-    t.grad.w = (dh0 <= p.clip) ? 0.5f * (gy2 - gy1) * ph / p.wh : 0.0f;
+    t.ctr_loss = t.ctr_grad = 0.0f;
+    if (p.coder == OD_CODER_BOXCODER) {
+        // through decode_single; clamp passes the gradient where the value is not above the bound
+        t.grad.x = (gx1 + gx2) * w / p.wx;
+        t.grad.y = (gy1 + gy2) * h / p.wy;
+        t.grad.z = (dw0 <= p.clip) ? 0.5f * (gx2 - gx1) * pw / p.ww : 0.0f;
+        t.grad.w = (dh0 <= p.clip) ? 0.5f * (gy2 - gy1) * ph / p.wh : 0.0f;
+    } else {
+        t.grad.x = -gx1 * w; t.grad.y = -gy1 * h; t.grad.z = gx2 * w; t.grad.w = gy2 * h;
+    }
     return t;
+}
+
+// FCOS centre-ness of an anchor matched to GT g: BoxLinearCoder.encode(anchor, gt) = (l, t, r, b) / (w, h, w, h),
+// target = sqrt( min(l, r) / max(l, r) * min(t, b) / max(t, b) ); loss = BCE-with-logits(x, target).
+__device__ __forceinline__ void ctrness_terms(float x, float4 a, float4 g, float& loss, float& grad) {
+    const float cx = 0.5f * (a.x + a.z), cy = 0.5f * (a.y + a.w);
+    const float w = a.z - a.x, h = a.w - a.y;
+    const float l = (cx - g.x) / w, tp = (cy - g.y) / h, r = (g.z - cx) / w, bt = (g.w - cy) / h;
+    const float z = sqrtf((fminf(l, r) / fmaxf(l, r)) * (fminf(tp, bt) / fmaxf(tp, bt)));
+    const float e = expf(-fabsf(x));
+    loss = (fmaxf(x, 0.0f) - x * z) + log1pf(e);
+    const float sg = (x >= 0.0f) ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    grad = sg - z;
 }
 
 __device__ __forceinline__ void l1_term(float d, float beta, float& loss, float& grad) {
@@ -506,6 +559,7 @@ __device__ __forceinline__ BoxTerms l1_terms(const BoxLossArgs& p, float4 r, flo
     l1_term(r.z - tw, p.beta, l2, t.grad.z);
     l1_term(r.w - th, p.beta, l3, t.grad.w);
     t.loss = ((l0 + l1) + l2) + l3;
+    t.ctr_loss = t.ctr_grad = 0.0f;
     return t;
 }
 
@@ -519,13 +573,18 @@ __device__ __forceinline__ bool box_terms_of(const BoxLossArgs& p, int b, long l
     const float4 an = *reinterpret_cast<const float4*>(p.anchors + (long long)b * p.anchor_stride + a * 4);
     const float4 g = *reinterpret_cast<const float4*>(p.gt_boxes + (long long)(m0 + m) * 4);
     t = (p.loss_type == OD_BOX_LOSS_GIOU) ? giou_terms(p, r, an, g) : l1_terms(p, r, an, g);
+    if (p.ctr) {
+        const float x = Elem<T>::to_float(((const T*)p.ctr)[(long long)b * p.ctr_stride + a]);
+        ctrness_terms(x, an, g, t.ctr_loss, t.ctr_grad);
+    }
     return true;
 }
 
 template <typename T>
 __global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, double* __restrict__ part_loss,
-                                                              int* __restrict__ part_fg) {
+                                                              double* __restrict__ part_ctr, int* __restrict__ part_fg) {
     __shared__ float s_sum[RT / 64];
+    __shared__ float s_ctr[RT / 64];
     __shared__ int s_fg[RT / 64];
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
@@ -537,36 +596,39 @@ __global__ __launch_bounds__(RT) void box_loss_forward_kernel(BoxLossArgs p, dou
         const long long a = a0 + it * RT + tid;
         m[it] = (a < p.n) ? __builtin_nontemporal_load(mrow + a) : -1;
     }
-    float acc = 0.0f;
+    float acc = 0.0f, acc_ctr = 0.0f;
     int fg = 0;
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
         BoxTerms t;
         if (box_terms_of<T>(p, b, a0 + it * RT + tid, m[it], t)) {
             acc += t.loss;
+            acc_ctr += t.ctr_loss;
             ++fg;
         }
     }
-    float wsum = acc;
+    float wsum = acc, wctr = acc_ctr;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wsum += __shfl_xor(wsum, o);
+    for (int o = 32; o > 0; o >>= 1) { wsum += __shfl_xor(wsum, o); wctr += __shfl_xor(wctr, o); }
     const int wfg = (int)wave_sum_all((uint32_t)fg);
-    if ((tid & 63) == 0) { s_sum[tid >> 6] = wsum; s_fg[tid >> 6] = wfg; }
+    if ((tid & 63) == 0) { s_sum[tid >> 6] = wsum; s_ctr[tid >> 6] = wctr; s_fg[tid >> 6] = wfg; }
     __syncthreads();
     if (tid == 0) {
-        double t = 0.0;
+        double t = 0.0, c = 0.0;
         int f = 0;
 #pragma unroll
-        for (int w = 0; w < RT / 64; ++w) { t += (double)s_sum[w]; f += s_fg[w]; }
+        for (int w = 0; w < RT / 64; ++w) { t += (double)s_sum[w]; c += (double)s_ctr[w]; f += s_fg[w]; }
         part_loss[(long long)b * p.blocks_per_image + blockIdx.x] = t;
+        if (part_ctr) part_ctr[(long long)b * p.blocks_per_image + blockIdx.x] = c;
         part_fg[(long long)b * p.blocks_per_image + blockIdx.x] = f;
     }
 }
 
 template <typename T>
 __global__ __launch_bounds__(RT) void box_loss_backward_kernel(BoxLossArgs p, const int* __restrict__ num_fg,
-                                                               const float* __restrict__ grad_out, int batch,
-                                                               T* __restrict__ grad_reg) {
+                                                               const float* __restrict__ grad_out,
+                                                               const float* __restrict__ grad_out_ctr, int batch,
+                                                               T* __restrict__ grad_reg, T* __restrict__ grad_ctr) {
     const int b = blockIdx.y;
     const int tid = threadIdx.x;
     const long long a0 = (long long)blockIdx.x * RCHUNK;
@@ -579,15 +641,23 @@ __global__ __launch_bounds__(RT) void box_loss_backward_kernel(BoxLossArgs p, co
         m[it] = (a < p.n) ? __builtin_nontemporal_load(mrow + a) : -1;
     }
     const int nf = num_fg[b];
-    const float scale = *grad_out / ((float)(nf > 1 ? nf : 1) * (float)batch);
+    const float denom = (float)(nf > 1 ? nf : 1) * (p.norm == OD_LOSS_NORM_PER_IMAGE ? (float)batch : 1.0f);
+    const float scale = *grad_out / denom;
+    const float scale_ctr = grad_ctr ? *grad_out_ctr / denom : 0.0f;
 #pragma unroll
     for (int it = 0; it < RPT; ++it) {
         const long long a = a0 + it * RT + tid;
         float4 gr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float gc = 0.0f;
         BoxTerms t;
-        if (box_terms_of<T>(p, b, a, m[it], t))
+        if (box_terms_of<T>(p, b, a, m[it], t)) {
             gr = make_float4(scale * t.grad.x, scale * t.grad.y, scale * t.grad.z, scale * t.grad.w);
-        if (a < p.n) *reinterpret_cast<typename Elem<T>::V*>(dst + a * 4) = Elem<T>::pack(gr);
+            gc = scale_ctr * t.ctr_grad;
+        }
+        if (a < p.n) {
+            *reinterpret_cast<typename Elem<T>::V*>(dst + a * 4) = Elem<T>::pack(gr);
+            if (grad_ctr) grad_ctr[(long long)b * p.n + a] = Elem<T>::from_float(gc);
+        }
     }
 }
 
@@ -597,7 +667,8 @@ bool box_loss_layout(int64_t n, int32_t batch, int* blocks, size_t* part_bytes, 
     if (blk > 0x7fffffff) return false;
     *blocks = (int)blk;
     *part_bytes = (((size_t)batch * (size_t)blk * sizeof(double)) + 255) & ~(size_t)255;
-    *total = *part_bytes + ((((size_t)batch * (size_t)blk * sizeof(int)) + 255) & ~(size_t)255);
+    // box partial sums, centre-ness partial sums, foreground counts
+    *total = 2 * *part_bytes + ((((size_t)batch * (size_t)blk * sizeof(int)) + 255) & ~(size_t)255);
     return true;
 }
 
@@ -630,6 +701,10 @@ int fill_box_args(BoxLossArgs* a, const void* reg, int32_t dtype, int64_t reg_st
     a->clip = clip;
     a->eps = eps;
     a->blocks_per_image = blocks;
+    a->coder = OD_CODER_BOXCODER;       // the FCOS entry points change these four
+    a->norm = OD_LOSS_NORM_PER_IMAGE;
+    a->ctr = nullptr;
+    a->ctr_stride = 0;
     return OD_OK;
 }
 
@@ -644,7 +719,8 @@ extern "C" size_t od_focal_loss_workspace_bytes(int64_t n, int32_t num_classes, 
 
 extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n, int32_t num_classes,
                                      const int64_t* matched, const int64_t* gt_labels, const int32_t* gt_offsets,
-                                     int32_t batch, float alpha, float gamma, float* loss, float* per_image_loss,
+                                     int32_t batch, float alpha, float gamma, int32_t normalization, float* loss,
+                                     float* per_image_loss,
                                      int32_t* num_foreground, void* workspace, size_t workspace_bytes, void* stream) {
     int blocks;
     size_t part, total;
@@ -654,7 +730,7 @@ extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int6
     if (workspace_bytes < total || ((uintptr_t)workspace & 255)) return OD_ERR_WORKSPACE;
     LossArgs a;
     const int rc = fill_args(&a, cls_logits, dtype, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha,
-                             gamma, blocks);
+                             gamma, normalization, blocks);
     if (rc != OD_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     double* part_loss = (double*)workspace;
@@ -676,7 +752,7 @@ extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int6
 #undef OD_FOCAL_FWD
     }
     hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
-                       blocks, (int)batch, loss, per_image_loss, num_foreground);
+                       blocks, (int)batch, (int)normalization, loss, per_image_loss, num_foreground);
     OD_LAUNCH_CHECK();
     return OD_OK;
 }
@@ -684,8 +760,8 @@ extern "C" int od_focal_loss_forward(const void* cls_logits, int32_t dtype, int6
 extern "C" int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int64_t batch_stride, int64_t n,
                                       int32_t num_classes, const int64_t* matched, const int64_t* gt_labels,
                                       const int32_t* gt_offsets, int32_t batch, float alpha, float gamma,
-                                      const int32_t* num_foreground, const float* grad_loss, void* grad_logits,
-                                      void* stream) {
+                                      int32_t normalization, const int32_t* num_foreground, const float* grad_loss,
+                                      void* grad_logits, void* stream) {
     int blocks;
     size_t part, total;
     if (!loss_layout(n, num_classes, batch, &blocks, &part, &total)) return OD_ERR_ARG;
@@ -694,7 +770,7 @@ extern "C" int od_focal_loss_backward(const void* cls_logits, int32_t dtype, int
     if ((uintptr_t)grad_logits & (elem_size(dtype) - 1)) return OD_ERR_ARG;
     LossArgs a;
     const int rc = fill_args(&a, cls_logits, dtype, batch_stride, n, num_classes, matched, gt_labels, gt_offsets, alpha,
-                             gamma, blocks);
+                             gamma, normalization, blocks);
     if (rc != OD_OK) return rc;
     if (blocks == 0) return OD_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -722,6 +798,53 @@ extern "C" size_t od_box_loss_workspace_bytes(int64_t n, int32_t batch) {
     return total > 0 ? total : 256;
 }
 
+namespace {
+
+// Forward of the regression-type losses: `a` complete; loss_ctr null unless a.ctr is set.
+int box_loss_forward_impl(const BoxLossArgs& a, int32_t dtype, int32_t batch, int blocks, size_t part, float* loss,
+                          float* loss_ctr, float* per_image_loss, int32_t* num_foreground, void* workspace,
+                          hipStream_t s) {
+    double* part_loss = (double*)workspace;
+    double* part_ctr = (double*)((char*)workspace + part);
+    int* part_fg = (int*)((char*)workspace + 2 * part);
+    if (blocks > 0) {
+        const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_BOX_FWD(T)                                                                                         \
+    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_FWD, (box_loss_forward_kernel<T>), grid, dim3(RT), 0, s, a, part_loss, \
+                     a.ctr ? part_ctr : (double*)nullptr, part_fg)
+        if (dtype == OD_DTYPE_F32) { OD_BOX_FWD(float); }
+        else if (dtype == OD_DTYPE_F16) { OD_BOX_FWD(_Float16); }
+        else { OD_BOX_FWD(bf16_t); }
+#undef OD_BOX_FWD
+    }
+    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
+                       blocks, (int)batch, a.norm, loss, per_image_loss, num_foreground);
+    if (a.ctr)
+        hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_ctr,
+                           (const int*)part_fg, blocks, (int)batch, a.norm, loss_ctr, (float*)nullptr, num_foreground);
+    OD_LAUNCH_CHECK();
+    return OD_OK;
+}
+
+int box_loss_backward_impl(const BoxLossArgs& a, int32_t dtype, int32_t batch, int blocks, const int32_t* num_foreground,
+                           const float* grad_loss, const float* grad_loss_ctr, void* grad_regression,
+                           void* grad_ctrness, hipStream_t s) {
+    if (blocks == 0) return OD_OK;
+    const dim3 grid((unsigned)blocks, (unsigned)batch);
+#define OD_BOX_BWD(T)                                                                                             \
+    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_BWD, (box_loss_backward_kernel<T>), grid, dim3(RT), 0, s, a, num_foreground, \
+                     grad_loss, grad_loss_ctr, (int)batch, (T*)grad_regression, (T*)grad_ctrness)
+    if (dtype == OD_DTYPE_F32) { OD_BOX_BWD(float); }
+    else if (dtype == OD_DTYPE_F16) { OD_BOX_BWD(_Float16); }
+    else { OD_BOX_BWD(bf16_t); }
+#undef OD_BOX_BWD
+    return OD_OK;
+}
+
+const float kUnitWeights[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+
+}  // namespace
+
 extern "C" int od_box_loss_forward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
                                    int64_t anchor_batch_stride, int64_t n, const int64_t* matched, const float* gt_boxes,
                                    const int32_t* gt_offsets, int32_t batch, int32_t loss_type, float beta,
@@ -738,23 +861,8 @@ extern "C" int od_box_loss_forward(const void* bbox_regression, int32_t dtype, i
     const int rc = fill_box_args(&a, bbox_regression, dtype, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
                                  gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
     if (rc != OD_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    double* part_loss = (double*)workspace;
-    int* part_fg = (int*)((char*)workspace + part);
-    if (blocks > 0) {
-        const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_BOX_FWD(T)                                                                                         \
-    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_FWD, (box_loss_forward_kernel<T>), grid, dim3(RT), 0, s, a, part_loss, \
-                     part_fg)
-        if (dtype == OD_DTYPE_F32) { OD_BOX_FWD(float); }
-        else if (dtype == OD_DTYPE_F16) { OD_BOX_FWD(_Float16); }
-        else { OD_BOX_FWD(bf16_t); }
-#undef OD_BOX_FWD
-    }
-    hipLaunchKernelGGL(focal_finalize_kernel, dim3(1), dim3(1024), 0, s, (const double*)part_loss, (const int*)part_fg,
-                       blocks, (int)batch, loss, per_image_loss, num_foreground);
-    OD_LAUNCH_CHECK();
-    return OD_OK;
+    return box_loss_forward_impl(a, dtype, batch, blocks, part, loss, nullptr, per_image_loss, num_foreground, workspace,
+                                 (hipStream_t)stream);
 }
 
 extern "C" int od_box_loss_backward(const void* bbox_regression, int32_t dtype, int64_t batch_stride, const float* anchors,
@@ -773,15 +881,59 @@ extern "C" int od_box_loss_backward(const void* bbox_regression, int32_t dtype, 
     const int rc = fill_box_args(&a, bbox_regression, dtype, batch_stride, anchors, anchor_batch_stride, n, matched, gt_boxes,
                                  gt_offsets, loss_type, beta, weights, bbox_xform_clip, eps, blocks);
     if (rc != OD_OK) return rc;
-    if (blocks == 0) return OD_OK;
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)blocks, (unsigned)batch);
-#define OD_BOX_BWD(T)                                                                                             \
-    OD_LAUNCH_KERNEL(OD_KERNEL_BOX_LOSS_BWD, (box_loss_backward_kernel<T>), grid, dim3(RT), 0, s, a, num_foreground, \
-                     grad_loss, (int)batch, (T*)grad_regression)
-    if (dtype == OD_DTYPE_F32) { OD_BOX_BWD(float); }
-    else if (dtype == OD_DTYPE_F16) { OD_BOX_BWD(_Float16); }
-    else { OD_BOX_BWD(bf16_t); }
-#undef OD_BOX_BWD
-    return OD_OK;
+    return box_loss_backward_impl(a, dtype, batch, blocks, num_foreground, grad_loss, nullptr, grad_regression, nullptr,
+                                  (hipStream_t)stream);
+}
+
+extern "C" int od_fcos_box_loss_forward(const void* bbox_regression, const void* bbox_ctrness, int32_t dtype,
+                                        int64_t reg_batch_stride, int64_t ctr_batch_stride, const float* anchors,
+                                        int64_t anchor_batch_stride, int64_t n, const int64_t* matched,
+                                        const float* gt_boxes, const int32_t* gt_offsets, int32_t batch, float eps,
+                                        float* loss_regression, float* loss_ctrness, int32_t* num_foreground,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    int blocks;
+    size_t part, total;
+    if (!box_loss_layout(n, batch, &blocks, &part, &total)) return OD_ERR_ARG;
+    if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
+    if (!loss_regression || !loss_ctrness || !num_foreground || !workspace || !bbox_ctrness) return OD_ERR_ARG;
+    if (workspace_bytes < total || ((uintptr_t)workspace & 255)) return OD_ERR_WORKSPACE;
+    if (ctr_batch_stride < n || elem_size(dtype) == 0 || ((uintptr_t)bbox_ctrness & (elem_size(dtype) - 1))) return OD_ERR_ARG;
+    BoxLossArgs a;
+    const int rc = fill_box_args(&a, bbox_regression, dtype, reg_batch_stride, anchors, anchor_batch_stride, n, matched,
+                                 gt_boxes, gt_offsets, OD_BOX_LOSS_GIOU, 0.0f, kUnitWeights, 0.0f, eps, blocks);
+    if (rc != OD_OK) return rc;
+    a.coder = OD_CODER_LINEAR;
+    a.norm = OD_LOSS_NORM_BATCH;
+    a.ctr = bbox_ctrness;
+    a.ctr_stride = ctr_batch_stride;
+    return box_loss_forward_impl(a, dtype, batch, blocks, part, loss_regression, loss_ctrness, nullptr, num_foreground,
+                                 workspace, (hipStream_t)stream);
+}
+
+extern "C" int od_fcos_box_loss_backward(const void* bbox_regression, const void* bbox_ctrness, int32_t dtype,
+                                         int64_t reg_batch_stride, int64_t ctr_batch_stride, const float* anchors,
+                                         int64_t anchor_batch_stride, int64_t n, const int64_t* matched,
+                                         const float* gt_boxes, const int32_t* gt_offsets, int32_t batch, float eps,
+                                         const int32_t* num_foreground, const float* grad_loss_regression,
+                                         const float* grad_loss_ctrness, void* grad_regression, void* grad_ctrness,
+                                         void* stream) {
+    int blocks;
+    size_t part, total;
+    if (!box_loss_layout(n, batch, &blocks, &part, &total)) return OD_ERR_ARG;
+    if (batch < 1 || batch > 65535) return batch == 0 ? OD_ERR_ARG : OD_ERR_LIMIT;
+    if (!num_foreground || !grad_loss_regression || !grad_loss_ctrness || !grad_regression || !grad_ctrness || !bbox_ctrness)
+        return OD_ERR_ARG;
+    if (elem_size(dtype) == 0 || ((uintptr_t)grad_regression & (4 * elem_size(dtype) - 1)) ||
+        ((uintptr_t)grad_ctrness & (elem_size(dtype) - 1)) || ctr_batch_stride < n)
+        return OD_ERR_ARG;
+    BoxLossArgs a;
+    const int rc = fill_box_args(&a, bbox_regression, dtype, reg_batch_stride, anchors, anchor_batch_stride, n, matched,
+                                 gt_boxes, gt_offsets, OD_BOX_LOSS_GIOU, 0.0f, kUnitWeights, 0.0f, eps, blocks);
+    if (rc != OD_OK) return rc;
+    a.coder = OD_CODER_LINEAR;
+    a.norm = OD_LOSS_NORM_BATCH;
+    a.ctr = bbox_ctrness;
+    a.ctr_stride = ctr_batch_stride;
+    return box_loss_backward_impl(a, dtype, batch, blocks, num_foreground, grad_loss_regression, grad_loss_ctrness,
+                                  grad_regression, grad_ctrness, (hipStream_t)stream);
 }

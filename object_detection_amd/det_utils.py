@@ -179,18 +179,20 @@ class _RetinaNetFocalLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
-                gamma: float) -> Tensor:
-        loss, _, num_fg = kernels.focal_loss_forward(cls_logits, matched, gt_labels, gt_offsets, alpha, gamma)
+                gamma: float, normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Tensor:
+        loss, _, num_fg = kernels.focal_loss_forward(cls_logits, matched, gt_labels, gt_offsets, alpha, gamma,
+                                                     normalization)
         ctx.save_for_backward(cls_logits, matched, gt_labels, gt_offsets, num_fg)
-        ctx.alpha, ctx.gamma = alpha, gamma
+        ctx.alpha, ctx.gamma, ctx.normalization = alpha, gamma, normalization
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         cls_logits, matched, gt_labels, gt_offsets, num_fg = ctx.saved_tensors
         g = grad_out.reshape(1).to(torch.float32).contiguous()
-        grad = kernels.focal_loss_backward(cls_logits, matched, gt_labels, gt_offsets, ctx.alpha, ctx.gamma, num_fg, g)
-        return grad, None, None, None, None, None
+        grad = kernels.focal_loss_backward(cls_logits, matched, gt_labels, gt_offsets, ctx.alpha, ctx.gamma, num_fg, g,
+                                           ctx.normalization)
+        return grad, None, None, None, None, None, None
 
 
 def _matched_rows(matched_idxs: List[Tensor], n: int) -> Tensor:
@@ -205,7 +207,8 @@ def _matched_rows(matched_idxs: List[Tensor], n: int) -> Tensor:
 
 
 def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor], labels: List[Tensor],
-                                  alpha: float = 0.25, gamma: float = 2.0) -> Optional[Tensor]:
+                                  alpha: float = 0.25, gamma: float = 2.0,
+                                  normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Optional[Tensor]:
     """Fused path of RetinaNetClassificationHead.compute_loss; None if the inputs do not qualify (not on the GPU,
     not fp32 / fp16 / bf16, or logits whose inner dimensions are not contiguous) and the caller should use the torch
     ops.  16-bit logits (a head running under autocast) are read as they are and the loss is evaluated in fp32."""
@@ -223,7 +226,8 @@ def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor]
     else:
         gt_labels = torch.zeros((1,), dtype=torch.int64, device=cls_logits.device)
     gt_offsets = kernels._device_ints(offsets, cls_logits.device)
-    return _RetinaNetFocalLoss.apply(cls_logits, matched, gt_labels, gt_offsets, float(alpha), float(gamma))
+    return _RetinaNetFocalLoss.apply(cls_logits, matched, gt_labels, gt_offsets, float(alpha), float(gamma),
+                                     int(normalization))
 
 
 class _RetinaNetBoxLoss(torch.autograd.Function):
@@ -284,3 +288,63 @@ def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: T
     eps = float(torch.finfo(bbox_regression.dtype).eps)  # as _box_loss: the epsilon of the regression's element type
     return _RetinaNetBoxLoss.apply(bbox_regression, anchor_table, matched, boxes, gt_offsets, _BOX_LOSS_TYPES[type], beta,
                                    tuple(float(w) for w in box_coder.weights), float(box_coder.bbox_xform_clip), eps)
+
+
+class _FCOSBoxLoss(torch.autograd.Function):
+    """Regression (GIoU) and centre-ness losses of the FCOS head for a whole batch (kernels.fcos_box_loss_*)."""
+
+    @staticmethod
+    def forward(ctx, bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: Tensor, matched: Tensor, gt_boxes: Tensor,
+                gt_offsets: Tensor, eps: float):
+        loss_reg, loss_ctr, num_fg = kernels.fcos_box_loss_forward(bbox_regression, bbox_ctrness, anchors, matched,
+                                                                   gt_boxes, gt_offsets, eps)
+        ctx.save_for_backward(bbox_regression, bbox_ctrness, anchors, matched, gt_boxes, gt_offsets, num_fg)
+        ctx.eps = eps
+        return loss_reg.reshape(()), loss_ctr.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_reg_loss: Tensor, grad_ctr_loss: Tensor):
+        bbox_regression, bbox_ctrness, anchors, matched, gt_boxes, gt_offsets, num_fg = ctx.saved_tensors
+        g_reg = grad_reg_loss.reshape(1).to(torch.float32).contiguous()
+        g_ctr = grad_ctr_loss.reshape(1).to(torch.float32).contiguous()
+        grad_reg, grad_ctr = kernels.fcos_box_loss_backward(bbox_regression, bbox_ctrness, anchors, matched, gt_boxes,
+                                                            gt_offsets, ctx.eps, num_fg, g_reg, g_ctr)
+        return grad_reg, grad_ctr.reshape(bbox_ctrness.shape), None, None, None, None, None
+
+
+def fcos_head_losses(cls_logits: Tensor, bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: List[Tensor],
+                     matched_idxs: List[Tensor], targets) -> Optional[dict]:
+    """Fused path of FCOSHead.compute_loss: {"classification", "bbox_regression", "bbox_ctrness"}; None if the inputs
+    do not qualify (not on the GPU, element types other than fp32 / fp16 / bf16, rows not contiguous) and the caller
+    should use the torch ops."""
+    ok = (cls_logits.is_cuda and cls_logits.dim() == 3 and bbox_regression.dim() == 3 and bbox_ctrness.dim() == 3
+          and cls_logits.dtype in _FUSED_DTYPES and bbox_regression.dtype is cls_logits.dtype
+          and bbox_ctrness.dtype is cls_logits.dtype and bbox_regression.shape[2] == 4 and bbox_ctrness.shape[2] == 1
+          and bbox_regression.stride(2) == 1 and bbox_regression.stride(1) == 4 and bbox_regression.stride(0) % 4 == 0
+          and bbox_regression.data_ptr() % (4 * bbox_regression.element_size()) == 0 and bbox_ctrness.stride(1) == 1
+          and not any(a.requires_grad for a in anchors) and not any(t["boxes"].requires_grad for t in targets))
+    if not ok:
+        return None
+    n = cls_logits.shape[1]
+    if any(a.shape != (n, 4) or a.dtype not in _FUSED_DTYPES for a in anchors):
+        return None
+    cls = retinanet_classification_loss(cls_logits, matched_idxs, [t["labels"] for t in targets],
+                                        normalization=_C.LOSS_NORM_BATCH)
+    if cls is None:
+        return None
+    first = anchors[0]
+    if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
+        anchor_table = first.float().contiguous()
+    else:
+        anchor_table = torch.stack([a.float() for a in anchors])
+    matched = _matched_rows(matched_idxs, n)
+    offsets = [0]
+    for t in targets:
+        offsets.append(offsets[-1] + t["boxes"].shape[0])
+    if offsets[-1] > 0:
+        boxes = torch.cat([t["boxes"].to(torch.float32).reshape(-1, 4) for t in targets])
+    else:
+        boxes = torch.zeros((1, 4), dtype=torch.float32, device=cls_logits.device)
+    gt_offsets = kernels._device_ints(offsets, cls_logits.device)
+    reg, ctr = _FCOSBoxLoss.apply(bbox_regression, bbox_ctrness, anchor_table, matched, boxes, gt_offsets, 1e-7)
+    return {"classification": cls, "bbox_regression": reg, "bbox_ctrness": ctr}

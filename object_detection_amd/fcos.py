@@ -83,6 +83,11 @@ class FCOSHead(nn.Module):
         cls_logits = head_outputs["cls_logits"]
         bbox_regression = head_outputs["bbox_regression"]
         bbox_ctrness = head_outputs["bbox_ctrness"]
+        if len(targets) > 0:
+            fused = det_utils.fcos_head_losses(cls_logits, bbox_regression, bbox_ctrness, list(anchors),
+                                               list(matched_idxs), targets)
+            if fused is not None:
+                return fused
         all_cls, all_boxes = [], []
         for t, m in zip(targets, matched_idxs):
             if len(t["labels"]) == 0:

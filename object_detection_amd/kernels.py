@@ -412,7 +412,7 @@ def _dtype_code(t: Tensor, what: str) -> int:
 
 
 def focal_loss_forward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
-                       gamma: float) -> Tuple[Tensor, Tensor, Tensor]:
+                       gamma: float, normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Tuple[Tensor, Tensor, Tensor]:
     """RetinaNet classification loss for a batch.  cls_logits [B,N,C] fp32 / fp16 / bf16 (inner dims contiguous), matched int64
     [B,N], gt_labels int64 [sum M], gt_offsets int32 [B+1].  Returns (loss [1], per_image [B], num_fg int32 [B])."""
     _require_gpu(cls_logits, "cls_logits")
@@ -425,20 +425,22 @@ def focal_loss_forward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, g
     num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
     rc = lib.od_focal_loss_forward(_ptr(cls_logits), _dtype_code(cls_logits, "cls_logits"), cls_logits.stride(0), n, C,
                                    _ptr(matched), _ptr(gt_labels),
-                                   _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(loss), _ptr(per_image),
+                                   _ptr(gt_offsets), B, float(alpha), float(gamma), int(normalization), _ptr(loss),
+                                   _ptr(per_image),
                                    _ptr(num_fg), _ptr(ws), ws.numel(), _stream(dev))
     _C.check(rc, "od_focal_loss_forward")
     return loss, per_image, num_fg
 
 
 def focal_loss_backward(cls_logits: Tensor, matched: Tensor, gt_labels: Tensor, gt_offsets: Tensor, alpha: float,
-                        gamma: float, num_fg: Tensor, grad_loss: Tensor) -> Tensor:
+                        gamma: float, num_fg: Tensor, grad_loss: Tensor,
+                        normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Tensor:
     dev = cls_logits.device
     B, n, C = cls_logits.shape
     grad = torch.empty((B, n, C), dtype=cls_logits.dtype, device=dev)
     rc = _C.lib().od_focal_loss_backward(_ptr(cls_logits), _dtype_code(cls_logits, "cls_logits"), cls_logits.stride(0), n, C,
                                          _ptr(matched), _ptr(gt_labels),
-                                         _ptr(gt_offsets), B, float(alpha), float(gamma), _ptr(num_fg),
+                                         _ptr(gt_offsets), B, float(alpha), float(gamma), int(normalization), _ptr(num_fg),
                                          _ptr(grad_loss), _ptr(grad), _stream(dev))
     _C.check(rc, "od_focal_loss_backward")
     return grad
@@ -504,3 +506,46 @@ def preprocess_images(images: Sequence[Tensor], resized: Sequence[Tuple[int, int
         _stream(dev))
     _C.check(rc, "od_preprocess_images")
     return out
+
+
+def _fcos_loss_call_args(bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: Tensor, matched: Tensor,
+                         gt_boxes: Tensor, gt_offsets: Tensor, eps: float):
+    B, n, _ = bbox_regression.shape
+    anchor_stride = 0 if anchors.dim() == 2 else anchors.stride(0)
+    return (_ptr(bbox_regression), _ptr(bbox_ctrness), _dtype_code(bbox_regression, "bbox_regression"),
+            bbox_regression.stride(0), bbox_ctrness.stride(0), _ptr(anchors), anchor_stride, n, _ptr(matched),
+            _ptr(gt_boxes), _ptr(gt_offsets), B, float(eps))
+
+
+def fcos_box_loss_forward(bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: Tensor, matched: Tensor,
+                          gt_boxes: Tensor, gt_offsets: Tensor, eps: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """FCOS regression (GIoU of the linearly decoded boxes) and centre-ness losses for a batch.  bbox_regression
+    [B,N,4], bbox_ctrness [B,N] (same element type), anchors [N,4] or [B,N,4] fp32, matched int64 [B,N].
+    Returns (loss_regression [1], loss_ctrness [1], num_fg int32 [B] = the batch total, repeated)."""
+    _require_gpu(bbox_regression, "bbox_regression")
+    dev = bbox_regression.device
+    B, n, _ = bbox_regression.shape
+    lib = _C.lib()
+    ws = _workspace(dev, "box_loss", lib.od_box_loss_workspace_bytes(n, B))
+    loss_reg = torch.empty((1,), dtype=torch.float32, device=dev)
+    loss_ctr = torch.empty((1,), dtype=torch.float32, device=dev)
+    num_fg = torch.empty((B,), dtype=torch.int32, device=dev)
+    args = _fcos_loss_call_args(bbox_regression, bbox_ctrness, anchors, matched, gt_boxes, gt_offsets, eps)
+    rc = lib.od_fcos_box_loss_forward(*args, _ptr(loss_reg), _ptr(loss_ctr), _ptr(num_fg), _ptr(ws), ws.numel(),
+                                      _stream(dev))
+    _C.check(rc, "od_fcos_box_loss_forward")
+    return loss_reg, loss_ctr, num_fg
+
+
+def fcos_box_loss_backward(bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: Tensor, matched: Tensor,
+                           gt_boxes: Tensor, gt_offsets: Tensor, eps: float, num_fg: Tensor, grad_reg_loss: Tensor,
+                           grad_ctr_loss: Tensor) -> Tuple[Tensor, Tensor]:
+    dev = bbox_regression.device
+    B, n, _ = bbox_regression.shape
+    grad_reg = torch.empty((B, n, 4), dtype=bbox_regression.dtype, device=dev)
+    grad_ctr = torch.empty((B, n), dtype=bbox_regression.dtype, device=dev)
+    args = _fcos_loss_call_args(bbox_regression, bbox_ctrness, anchors, matched, gt_boxes, gt_offsets, eps)
+    rc = _C.lib().od_fcos_box_loss_backward(*args, _ptr(num_fg), _ptr(grad_reg_loss), _ptr(grad_ctr_loss), _ptr(grad_reg),
+                                            _ptr(grad_ctr), _stream(dev))
+    _C.check(rc, "od_fcos_box_loss_backward")
+    return grad_reg, grad_ctr

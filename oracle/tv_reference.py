@@ -550,6 +550,53 @@ def fcos_match(targets_boxes: List[Tensor], anchors: List[Tensor], num_anchors_p
     return out
 
 
+def fcos_head_loss(targets, head_outputs, anchors, matched_idxs):
+    """torchvision FCOSHead.compute_loss: focal classification, GIoU of the linearly decoded boxes and BCE of the
+    centre-ness against its encoded target, each summed over the batch and divided by max(1, #foreground)."""
+    cls_logits = head_outputs["cls_logits"]
+    bbox_regression = head_outputs["bbox_regression"]
+    bbox_ctrness = head_outputs["bbox_ctrness"]
+    all_gt_classes_targets, all_gt_boxes_targets = [], []
+    for targets_per_image, matched_idxs_per_image in zip(targets, matched_idxs):
+        if len(targets_per_image["labels"]) == 0:
+            gt_classes_targets = targets_per_image["labels"].new_zeros((len(matched_idxs_per_image),))
+            gt_boxes_targets = targets_per_image["boxes"].new_zeros((len(matched_idxs_per_image), 4))
+        else:
+            gt_classes_targets = targets_per_image["labels"][matched_idxs_per_image.clip(min=0)]
+            gt_boxes_targets = targets_per_image["boxes"][matched_idxs_per_image.clip(min=0)]
+        gt_classes_targets[matched_idxs_per_image < 0] = -1
+        all_gt_classes_targets.append(gt_classes_targets)
+        all_gt_boxes_targets.append(gt_boxes_targets)
+    all_gt_boxes_targets = torch.stack(all_gt_boxes_targets)
+    all_gt_classes_targets = torch.stack(all_gt_classes_targets)
+    anchors = torch.stack(anchors)
+    foregroud_mask = all_gt_classes_targets >= 0
+    num_foreground = foregroud_mask.sum().item()
+    gt_classes_targets = torch.zeros_like(cls_logits)
+    gt_classes_targets[foregroud_mask, all_gt_classes_targets[foregroud_mask]] = 1.0
+    loss_cls = sigmoid_focal_loss(cls_logits, gt_classes_targets, reduction="sum")
+    coder = BoxLinearCoder(normalize_by_size=True)
+    pred_boxes = coder.decode(bbox_regression, anchors)
+    loss_bbox_reg = generalized_box_iou_loss(pred_boxes[foregroud_mask], all_gt_boxes_targets[foregroud_mask],
+                                             reduction="sum")
+    bbox_reg_targets = coder.encode(anchors, all_gt_boxes_targets)
+    if len(bbox_reg_targets) == 0:
+        gt_ctrness_targets = bbox_reg_targets.new_zeros(bbox_reg_targets.size()[:-1])
+    else:
+        left_right = bbox_reg_targets[:, :, [0, 2]]
+        top_bottom = bbox_reg_targets[:, :, [1, 3]]
+        gt_ctrness_targets = torch.sqrt((left_right.min(dim=-1)[0] / left_right.max(dim=-1)[0])
+                                        * (top_bottom.min(dim=-1)[0] / top_bottom.max(dim=-1)[0]))
+    pred_centerness = bbox_ctrness.squeeze(dim=2)
+    loss_bbox_ctrness = torch.nn.functional.binary_cross_entropy_with_logits(
+        pred_centerness[foregroud_mask], gt_ctrness_targets[foregroud_mask], reduction="sum")
+    return {
+        "classification": loss_cls / max(1, num_foreground),
+        "bbox_regression": loss_bbox_reg / max(1, num_foreground),
+        "bbox_ctrness": loss_bbox_ctrness / max(1, num_foreground),
+    }
+
+
 def fcos_postprocess(head_outputs: Dict[str, List[Tensor]], anchors: List[List[Tensor]],
                      image_shapes: List[Tuple[int, int]], score_thresh: float, topk_candidates: int,
                      nms_thresh: float, detections_per_img: int, math: str = "spec",

@@ -76,10 +76,13 @@ def test_argument_errors_of_loss_transform_and_planar_entries():
     assert lib.od_focal_loss_workspace_bytes(786240, 4, 16) >= 16 * 768 * 12
     assert lib.od_focal_loss_workspace_bytes(-1, 4, 16) == 0
     # unknown element type, null logits, workspace too small
-    assert lib.od_focal_loss_forward(p16, 7, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 1 << 20, null) == -1
-    assert lib.od_focal_loss_forward(null, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 1 << 20, null) == -1
-    assert lib.od_focal_loss_forward(p16, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, p16, p16, p16, p256, 8, null) == -3
-    assert lib.od_focal_loss_backward(p16, 1, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, null, p16, p16, null) == -1
+    assert lib.od_focal_loss_forward(p16, 7, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, 0, p16, p16, p16, p256, 1 << 20, null) == -1
+    assert lib.od_focal_loss_forward(null, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, 0, p16, p16, p16, p256, 1 << 20, null) == -1
+    assert lib.od_focal_loss_forward(p16, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, 5, p16, p16, p16, p256, 1 << 20, null) == -1
+    assert lib.od_focal_loss_forward(p16, 0, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, 1, p16, p16, p16, p256, 8, null) == -3
+    assert lib.od_focal_loss_backward(p16, 1, 40, 10, 4, p16, p16, p16, 1, 0.25, 2.0, 0, null, p16, p16, null) == -1
+    assert lib.od_fcos_box_loss_forward(p16, null, 0, 40, 10, p16, 0, 10, p16, p16, p16, 1, 1e-7, p16, p16, p16, p256,
+                                        1 << 20, null) == -1                          # centre-ness missing
     w = (ctypes.c_float * 4)(1.0, 1.0, 1.0, 1.0)
     zero_w = (ctypes.c_float * 4)(1.0, 0.0, 1.0, 1.0)
     assert lib.od_box_loss_workspace_bytes(1000, 2) > 0

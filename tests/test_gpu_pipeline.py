@@ -137,6 +137,29 @@ def test_fcos_postprocess_and_match(device):
         assert torch.equal(g.cpu(), w)
 
 
+def test_fcos_training_step_end_to_end(device):
+    """model(images, targets) of the FCOS model in train mode: the three losses come from the fused kernels, are
+    finite, and backpropagate into the head parameters; also under autocast."""
+    torch.manual_seed(1)
+    model = get_model(4, arch="fcos", backbone="pyramid_stub", out_channels=32, min_size=128, max_size=128).to(device)
+    images = [torch.rand(3, 128, 128, device=device), torch.rand(3, 100, 120, device=device)]
+    targets = [{"boxes": torch.tensor([[10., 10., 60., 70.], [30., 40., 90., 100.]], device=device),
+                "labels": torch.tensor([1, 2], device=device)},
+               {"boxes": torch.zeros((0, 4), device=device), "labels": torch.zeros((0,), dtype=torch.int64, device=device)}]
+    model.train()
+    for amp in (False, True):
+        model.zero_grad()
+        with torch.autocast("cuda", dtype=torch.float16, enabled=amp):
+            losses = model(images, targets)
+        assert set(losses) == {"classification", "bbox_regression", "bbox_ctrness"}
+        for k, v in losses.items():
+            assert v.dtype is torch.float32 and bool(torch.isfinite(v)), k
+            assert type(v.grad_fn).__name__.startswith(("_RetinaNetFocalLoss", "_FCOSBoxLoss")), (k, type(v.grad_fn).__name__)
+        sum(losses.values()).backward()
+        g = model.head.regression_head.bbox_ctrness.weight.grad
+        assert g is not None and bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+
+
 def test_fcos_full_size_cfg3(device):
     """The FCOS configuration as specified (16 images, 1024 x 1024, 21 824 locations, 200 GT each): centre-sampling
     matches and detections of every image against the CPU checker, bit for bit."""
@@ -213,6 +236,44 @@ def test_eval_forward_reads_head_maps_in_place(device, arch):
     for d, r in zip(dets, ref):
         for k in ("boxes", "scores", "labels"):
             assert torch.equal(d[k], r[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fcos_fused_head_losses(device, dtype):
+    """FCOSHead.compute_loss on the GPU goes through the fused kernels (classification normalised by the batch's
+    foreground count, GIoU of the linearly decoded boxes, centre-ness BCE) and agrees with the torch restatement
+    evaluated in fp32 on the CPU from the same values: losses 1e-5 relative, gradients 1e-5 of their largest entry
+    plus 1e-4 relative per element (plus one rounding of the element type for 16-bit gradients)."""
+    cfg = dataclasses.replace(synthetic.CFG3, batch=3, image_size=(512, 512), grids=(64, 32, 16, 8, 4), num_gt=40,
+                              cfg_id=31)
+    model = _model(cfg, device, arch="fcos")
+    anchors_dev = torch.cat(_anchors(model, cfg, device))
+    anchors = anchors_dev.cpu()
+    sizes = synthetic.level_sizes(cfg)
+    head = synthetic.make_head_outputs(cfg, with_ctrness=True)
+    head["bbox_regression"] = head["bbox_regression"].abs()
+    head = {k: v.to(dtype) for k, v in head.items()}
+    targets = synthetic.make_targets(cfg, empty_image=2)
+    matched = tv.fcos_match([t["boxes"] for t in targets], [anchors] * cfg.batch, sizes, 1.5)
+    assert int(sum((m >= 0).sum() for m in matched)) > 0
+    ref_in = {k: v.float().clone().requires_grad_(True) for k, v in head.items()}
+    ref = tv.fcos_head_loss(targets, ref_in, [anchors] * cfg.batch, matched)
+    (ref["classification"] + 2.0 * ref["bbox_regression"] + 3.0 * ref["bbox_ctrness"]).backward()
+    dev_in = {k: v.to(device).requires_grad_(True) for k, v in head.items()}
+    t_dev = [{k: v.to(device) for k, v in t.items()} for t in targets]
+    got = model.head.compute_loss(t_dev, dev_in, [anchors_dev] * cfg.batch, [m.to(device) for m in matched])
+    for k in ref:
+        assert got[k].grad_fn is not None and type(got[k].grad_fn).__name__.startswith(("_RetinaNetFocalLoss", "_FCOSBoxLoss")), k
+        assert abs(got[k].item() - ref[k].item()) <= 1e-5 * abs(ref[k].item()), (k, got[k].item(), ref[k].item())
+    (got["classification"] + 2.0 * got["bbox_regression"] + 3.0 * got["bbox_ctrness"]).backward()
+    ulp = float(torch.finfo(dtype).eps) if dtype is not torch.float32 else 0.0
+    spacing = 2.0 ** -24 if dtype is torch.float16 else 0.0
+    for k in ref_in:
+        g, w = dev_in[k].grad, ref_in[k].grad
+        assert g.dtype is dtype and g.shape == w.shape
+        g = g.float().cpu()
+        tol = 1e-5 * w.abs().max() + (1e-4 + ulp) * w.abs() + spacing
+        assert bool(((g - w).abs() <= tol).all()), (k, float((g - w).abs().max()))
 
 
 def test_training_step_under_autocast(device):
