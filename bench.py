@@ -343,6 +343,10 @@ def main():
                 "algorithmic_MB_per_launch": abytes / 1e6,
                 # the same kernel with the GPU to itself (single-stream probe before the timed region): in the
                 # timed region steps on other streams run beside it and stretch it
+                # matching only: 13 fp32 operations per (anchor, GT) pair of the brute-force formulation against the
+                # non-FMA VALU peak (78.6 Tops/s); above 1 because the kernels skip the pairs whose boxes cannot overlap
+                "valu_frac_bruteforce_equivalent": (13.0 * cfg.batch * cfg.num_anchors * cfg.num_gt / dur_s / 78.6e12
+                                                    if dominant.startswith("match") and dur_s > 0 else None),
                 "launch_us_alone": probe[dominant]["ms_per_launch"] * 1e3,
                 "frac_alone": (abytes / (probe[dominant]["ms_per_launch"] * 1e-3) / 1e9) / HBM_PEAK_GBS,
             },
