@@ -223,17 +223,21 @@ def test_select_candidates(device, coder):
     assert int(cc[:, 0].min()) == K   # the finest level saturates top-k (ties at score 1.0 included)
 
 
-def _check_select_single_level(device, logits, C, thr, K):
-    """One level, batch of logits [B, N, C]: indices and scores of the top-k against the scalar checker."""
+def _check_select_single_level(device, logits, C, thr, K, ctrness=None):
+    """One level, batch of logits [B, N, C] (and FCOS centre-ness [B, N, 1]): indices and scores of the top-k against
+    the scalar checker."""
     B, N = logits.shape[0], logits.shape[1]
     reg = torch.zeros((B, N, 4))
     anchors = torch.tensor([[0., 0., 8., 8.]]).repeat(N, 1)
     hw = torch.tensor([[64, 64]] * B, dtype=torch.int32, device=device)
     cb, cs, cl, ci, cc = kernels.select_candidates([logits.to(device)], [reg.to(device)], [anchors.to(device)], hw, thr, K,
-                                                   _C.CODER_BOXCODER, math.log(1000.0 / 16), want_index=True)
+                                                   _C.CODER_BOXCODER if ctrness is None else _C.CODER_LINEAR,
+                                                   math.log(1000.0 / 16), want_index=True,
+                                                   ctr_levels=None if ctrness is None else [ctrness.to(device)])
     cs, ci, cc = cs.cpu(), ci.cpu(), cc.cpu()
     for b in range(B):
-        s_ref, i_ref = c_oracle.filter_topk(logits[b].numpy(), None, C, thr, K)
+        s_ref, i_ref = c_oracle.filter_topk(logits[b].numpy(), None if ctrness is None else ctrness[b].numpy().reshape(-1),
+                                            C, thr, K)
         n = int(cc[b, 0])
         assert n == len(s_ref), (b, n, len(s_ref))
         assert np.array_equal(ci[b, :n].numpy(), i_ref), b
@@ -532,3 +536,10 @@ def test_select_sampled_bound_large_levels(device):
     _check_select_single_level(device, torch.full((1, N, C), 0.25), C, 0.5, 1000)
     _check_select_single_level(device, dense[:1], C, 0.0, 500)
     _check_select_single_level(device, dense[:1], C, -1.0, 500)
+    # FCOS scores (sqrt of class and centre-ness sigmoids) are not a function of the class logit alone: the sample is
+    # ranked by score
+    Nf, Cf = 140003, 2
+    fl = torch.empty((2, Nf, Cf)).normal_(-1.0, 1.5, generator=gen)
+    fc = torch.empty((2, Nf, 1)).normal_(0.0, 1.0, generator=gen)
+    _check_select_single_level(device, fl, Cf, 0.2, 1000, ctrness=fc)
+    _check_select_single_level(device, fl, Cf, 0.6, 300, ctrness=fc)
