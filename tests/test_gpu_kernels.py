@@ -421,14 +421,18 @@ def test_box_loss_kernels(device, loss_type, n, shared_anchors):
         assert float(grad[0, ::97, 2].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("num_anchors,num_classes,with_ctr", [(9, 4, False), (3, 91, False), (1, 5, True), (2, 3, True)])
-def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors, num_classes, with_ctr):
+@pytest.mark.parametrize("num_anchors,num_classes,with_ctr,large", [(9, 4, False, False), (3, 91, False, False),
+                                                                    (1, 5, True, False), (2, 3, True, False),
+                                                                    (9, 4, False, True), (2, 3, True, True)])
+def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors, num_classes, with_ctr, large):
     """od_select_candidates_planar on the convolution layout [B, A*K, H, W] returns exactly what
     od_select_candidates returns on the permuted [B, H*W*A, K] copies (boxes, scores, labels, flat indices, counts),
     for square and ragged planes, chunks that end inside a plane and planes smaller than a chunk."""
     g = torch.Generator().manual_seed(77 + num_anchors + num_classes)
     B, K = 3, 200
-    planes = [(48, 40), (17, 23), (6, 5), (1, 1)]
+    # `large`: a level big enough for the sampled score bound, whose sample positions go through the same
+    # position -> flat index conversion
+    planes = [(200, 168), (6, 5)] if large else [(48, 40), (17, 23), (6, 5), (1, 1)]
     A, C = num_anchors, num_classes
 
     def permuted(m, per_anchor):
