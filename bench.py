@@ -235,7 +235,13 @@ def main():
             spin["first_batch_ms_per_step"] = 1e3 * cur
         spin["last_batch_ms_per_step"] = 1e3 * cur
         waited = time.perf_counter() - t_spin
-        if (prev is not None and abs(cur - prev) <= 0.05 * prev and waited >= 1.0) or waited >= 20.0:
+        stop = (prev is not None and abs(cur - prev) <= 0.05 * prev and waited >= 1.0) or waited >= 20.0
+        if world > 1:                                     # the steps contain a collective: every rank runs the same number
+            import torch.distributed as dist
+            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stop = bool(flag.item()) or spin["batches"] >= 2000
+        if stop:
             break
         prev = cur
     spin["seconds"] = time.perf_counter() - t_spin
