@@ -134,10 +134,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the multi-rank control flow on a machine with one GPU: OD_BENCH_REHEARSAL=1 puts every rank on GPU 0
+    # and uses the gloo backend (numbers from such a run mean nothing)
+    rehearsal = bool(os.environ.get("OD_BENCH_REHEARSAL"))
+    if rehearsal:
+        import faulthandler
+        faulthandler.dump_traceback_later(150, exit=True)      # a hang ends with the stack of every thread
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
@@ -235,16 +245,20 @@ def main():
             spin["first_batch_ms_per_step"] = 1e3 * cur
         spin["last_batch_ms_per_step"] = 1e3 * cur
         waited = time.perf_counter() - t_spin
-        stop = (prev is not None and abs(cur - prev) <= 0.05 * prev and waited >= 1.0) or waited >= 20.0
+        stop = (prev is not None and abs(cur - prev) <= 0.05 * prev and waited >= 1.0) or waited >= (2.0 if rehearsal else 20.0)
+        if rehearsal:
+            print(f"[rank {rank}] spin-up batch {spin['batches']}: {1e3 * cur:.3f} ms/step", file=sys.stderr, flush=True)
         if world > 1:                                     # the steps contain a collective: every rank runs the same number
             import torch.distributed as dist
-            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device=dev)
+            flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             stop = bool(flag.item()) or spin["batches"] >= 2000
         if stop:
             break
         prev = cur
     spin["seconds"] = time.perf_counter() - t_spin
+    if rehearsal:
+        print(f"[rank {rank}] spin-up done: {spin}", file=sys.stderr, flush=True)
 
     for i in range(max(args.warmup, 2)):                  # the W warm-up steps of the contract
         step(i % counts_host.shape[0])
@@ -281,6 +295,8 @@ def main():
         step(i)
     host_enqueue = time.perf_counter() - t0               # the host's share: all launches issued, GPU possibly still busy
     sync()
+    if rehearsal:
+        print(f"[rank {rank}] timed region done", file=sys.stderr, flush=True)
     total_detections = int(counts_host[:args.steps].sum())      # the host reads every step's counts here
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = _C.profile_read(dom_id)
@@ -318,7 +334,7 @@ def main():
 
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

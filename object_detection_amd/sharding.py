@@ -46,6 +46,10 @@ def all_gather_detections(packed: Tensor, counts: Tensor, group=None) -> Tuple[T
     B = packed.shape[0]
     # one message per rank: the detections of an image followed by its count (exact in fp32: counts <= D < 2^24)
     local = torch.cat((packed.reshape(B, -1), counts.to(packed.dtype).reshape(B, 1)), dim=1).contiguous()
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"      # gloo exchanges host memory
+    device = local.device
+    if staged:
+        local = local.cpu()
     gathered = local.new_empty((world * B, local.shape[1]))
     try:
         dist.all_gather_into_tensor(gathered, local, group=group)
@@ -53,6 +57,8 @@ def all_gather_detections(packed: Tensor, counts: Tensor, group=None) -> Tuple[T
         parts = [torch.empty_like(local) for _ in range(world)]
         dist.all_gather(parts, local, group=group)
         gathered = torch.cat(parts)
+    if staged:
+        gathered = gathered.to(device)
     g_packed = gathered[:, :-1].reshape((world * B,) + tuple(packed.shape[1:]))
     g_counts = gathered[:, -1].to(counts.dtype)
     return g_packed, g_counts
