@@ -52,7 +52,7 @@ def pmc_traffic(kernel: str):
 
 
 def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
-    """Minimal bytes one launch must move (per batch of cfg.batch images); formulas in DESIGN.md."""
+    """Minimal bytes one launch must move (per batch of cfg.batch images): every input read once, every output written once."""
     B, N, C, M = cfg.batch, cfg.num_anchors, cfg.num_classes, cfg.num_gt
     L, K, D = len(cfg.grids), cfg.topk_candidates, cfg.detections_per_img
     return {
