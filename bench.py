@@ -195,8 +195,7 @@ def main():
                                               model.detections_per_img, _C.CODER_BOXCODER,
                                               model.box_coder.bbox_xform_clip, return_padded=True)
         if world > 1:
-            packed = sharding.pack_detections(ob, os_, ol)
-            sharding.all_gather_detections(packed, oc)
+            sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
         if sync_host:
             oc.tolist()
         else:

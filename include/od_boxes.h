@@ -178,6 +178,17 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
                    size_t workspace_bytes, void* stream);
 
 /*
+ * Message of the detections all-gather: the padded outputs of od_batched_nms for the local images, packed into
+ * one fp32 row per image so that one collective moves them.  No counterpart in the reference, which runs one
+ * process on one device (train.py:24, predict.py:25); this is the only exchange of the image-sharded pipeline.
+ *   boxes fp32 [batch, max_det, 4], scores fp32 [batch, max_det], labels int64 [batch, max_det] (values below 2^24
+ *   are exact in fp32), counts int32 [batch]  ->  message fp32 [batch, 6*max_det + 1]: max_det rows
+ *   (x1, y1, x2, y2, score, label) followed by the count.
+ */
+int od_pack_detections(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
+                       int32_t batch, int32_t max_det, float* message, void* stream);
+
+/*
  * Classification loss of the RetinaNet head, fused with its target construction.  Replaces torchvision
  * RetinaNetClassificationHead.compute_loss = per image sigmoid_focal_loss(logits[valid], target[valid], "sum")
  * / max(1, #foreground), averaged over the batch (head built at reference retinanet_model.py:47-54, loss taken at
@@ -309,7 +320,8 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_PREPROCESS 16
 #define OD_KERNEL_SAMPLE 17         /* od_select_candidates: sampled score bound per (image, level)   */
 #define OD_KERNEL_FILTER_REDO 18    /* od_select_candidates: second filter pass (normally exits at once) */
-#define OD_KERNEL_COUNT 19
+#define OD_KERNEL_PACK 19           /* od_pack_detections */
+#define OD_KERNEL_COUNT 20
 int od_profile_select(int32_t kernel_id);
 /* Time only every `every`-th launch of a selected kernel (default 1): a timed launch costs the host tens of
  * microseconds, which a throughput measurement should not pay on every step. */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "od_pack_detections": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "od_focal_loss_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "od_focal_loss_forward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,
                                         c_int32, _P, _P, _P, _P, c_size_t, _P]),
@@ -70,7 +71,8 @@ SIGNATURES = {
 
 PROFILE_OFF, PROFILE_ALL = -1, -2
 KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
-                "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo"]
+                "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo",
+                "pack"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 LOSS_NORM_PER_IMAGE, LOSS_NORM_BATCH = 0, 1

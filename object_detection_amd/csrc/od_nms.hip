@@ -73,9 +73,10 @@ struct NmsArgs {
 };
 
 // intersection area exactly as nms_kernel.cpp: max(0, min(x2) - max(x1)) * max(0, min(y2) - max(y1))
+// (bare v_min / v_max on the coordinates: fminf / fmaxf would first quiet every operand read from memory)
 __device__ __forceinline__ float intersection(const float4 i, const float4 j) {
-    const float xx1 = fmaxf(i.x, j.x), yy1 = fmaxf(i.y, j.y);
-    const float xx2 = fminf(i.z, j.z), yy2 = fminf(i.w, j.w);
+    const float xx1 = hw_max(i.x, j.x), yy1 = hw_max(i.y, j.y);
+    const float xx2 = hw_min(i.z, j.z), yy2 = hw_min(i.w, j.w);
     const float w = fmaxf(0.0f, xx2 - xx1), h = fmaxf(0.0f, yy2 - yy1);
     return w * h;
 }
@@ -86,18 +87,19 @@ __device__ __forceinline__ bool over_threshold_exact(float inter, float iarea, f
     return ovr >= thr_up;
 }
 
-// Same decision without the IEEE division in the common case: the 1-ulp hardware reciprocal gives
-// ovr to ~4e-7 relative; a value outside the band thr_up*(1 +- 1e-5) decides at once, anything inside
-// it (or NaN / non-positive thresholds, where the band test is not valid) takes the exact division.
-// The branch is wave-uniform so the exact path costs nothing unless some lane needs it.
+// Same decision without the IEEE division in the common case: ovr >= thr_up is decided by comparing inter with
+// thr_up*(1 +- 1e-5)*den (two multiplications, no reciprocal).  Outside that band the rounding of the products
+// (2^-24 relative) cannot change the outcome of the exact division; anything inside it, a product that is not a
+// normal finite positive number (degenerate or huge boxes, NaN) and thresholds for which the band is not valid
+// take the exact division.  The branch is wave-uniform, so the exact path costs nothing unless some lane needs it.
 struct ThrBand { float up, lo, hi; bool usable; };
 __device__ __forceinline__ bool over_threshold(float inter, float iarea, float jarea, const ThrBand& t) {
     const float den = (iarea + jarea) - inter;
-    const float approx = inter * __builtin_amdgcn_rcpf(den);
-    const bool above = approx >= t.hi, below = approx <= t.lo;
+    const float ph = t.hi * den, pl = t.lo * den;
+    const bool above = inter >= ph, below = inter <= pl;
+    const bool safe = (pl > 1e-30f) && (ph < 1e38f);
     bool res = above;
-    // den below 1e-30 (degenerate boxes): the reciprocal may flush or overflow, decide exactly
-    if (__ballot(!(above || below) || !(den > 1e-30f) || !t.usable) != 0) res = (inter / den) >= t.up;
+    if (__ballot(!(above || below) || !safe || !t.usable) != 0) res = (inter / den) >= t.up;
     return res;
 }
 
@@ -524,6 +526,24 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     STAMP(31);
 }
 
+// one thread per padded detection slot: six floats of the message row; thread 0 of an image appends the count
+__global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ boxes, const float* __restrict__ scores,
+                                                   const long long* __restrict__ labels, const int* __restrict__ counts,
+                                                   int max_det, float* __restrict__ message) {
+    const int b = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    float* row = message + (long long)b * (6ll * max_det + 1);
+    if (k < max_det) {
+        const long long i = (long long)b * max_det + k;
+        const float4 bx = boxes[i];
+        float* o = row + 6ll * k;
+        o[0] = bx.x; o[1] = bx.y; o[2] = bx.z; o[3] = bx.w;
+        o[4] = scores[i];
+        o[5] = (float)labels[i];
+    }
+    if (k == 0) row[6ll * max_det] = (float)counts[b];
+}
+
 int next_pow2(int v) {
     int p = 64;
     while (p < v) p <<= 1;
@@ -582,5 +602,18 @@ extern "C" int od_batched_nms(const float* boxes, const float* scores, const int
         return OD_OK;
     }
     OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
+    return OD_OK;
+}
+
+extern "C" int od_pack_detections(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
+                                  int32_t batch, int32_t max_det, float* message, void* stream) {
+    if (batch < 0 || max_det < 0) return OD_ERR_ARG;
+    if (batch == 0) return OD_OK;
+    if (!counts || !message || (max_det > 0 && (!boxes || !scores || !labels))) return OD_ERR_ARG;
+    if (batch > 65535) return OD_ERR_LIMIT;
+    if ((uintptr_t)boxes & 15) return OD_ERR_ARG;
+    const unsigned gx = (unsigned)((max_det + 255) / 256);
+    OD_LAUNCH_KERNEL(OD_KERNEL_PACK, pack_kernel, dim3(gx > 0 ? gx : 1u, (unsigned)batch), dim3(256), 0,
+                     (hipStream_t)stream, (const float4*)boxes, scores, (const long long*)labels, counts, max_det, message);
     return OD_OK;
 }

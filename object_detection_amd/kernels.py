@@ -400,6 +400,34 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
     return keep_idx, out_boxes, out_scores, out_labels, out_count
 
 
+def pack_detections(boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """Padded detections of the local images -> the all-gather message, fp32 [B, 6*D + 1] (one launch).
+
+    boxes [B, D, 4] fp32, scores [B, D] fp32, labels [B, D] int64, counts [B] int32 (the outputs of
+    ``batched_nms_padded``).  Row layout: D rows (x1, y1, x2, y2, score, label), then the count."""
+    _require_gpu(boxes, "boxes")
+    dev = boxes.device
+    B, D = int(boxes.shape[0]), int(boxes.shape[1])
+    if tuple(boxes.shape) != (B, D, 4) or tuple(scores.shape) != (B, D) or tuple(labels.shape) != (B, D) \
+            or tuple(counts.shape) != (B,):
+        raise ValueError(f"pack_detections: inconsistent shapes {tuple(boxes.shape)}, {tuple(scores.shape)}, "
+                         f"{tuple(labels.shape)}, {tuple(counts.shape)}")
+    if labels.dtype != torch.int64 or counts.dtype != torch.int32:
+        raise TypeError("pack_detections: labels must be int64 and counts int32")
+    for name, t in (("scores", scores), ("labels", labels), ("counts", counts)):
+        if t.device != dev:
+            raise RuntimeError(f"pack_detections: {name} is on {t.device}, boxes on {dev}")
+    boxes, scores = _f32c(boxes), _f32c(scores)
+    if out is None:
+        out = torch.empty((B, 6 * D + 1), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (B, 6 * D + 1) or out.dtype != torch.float32 or out.device != dev or not out.is_contiguous():
+        raise ValueError("pack_detections: `out` must be a contiguous fp32 [B, 6*D + 1] tensor on the inputs' device")
+    rc = _C.lib().od_pack_detections(_ptr(boxes), _ptr(scores), _ptr(labels.contiguous()), _ptr(counts.contiguous()),
+                                     B, D, _ptr(out), _stream(dev))
+    _C.check(rc, "od_pack_detections")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 _DTYPE_CODES = {torch.float32: _C.DTYPE_F32, torch.float16: _C.DTYPE_F16, torch.bfloat16: _C.DTYPE_BF16}
 

@@ -9,7 +9,7 @@ what replaces "run it on one device" when eight GPUs of a node are available.
 """
 from __future__ import annotations
 
-from typing import List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,10 +29,33 @@ def pack_detections(boxes: Tensor, scores: Tensor, labels: Tensor) -> Tensor:
 
 
 def unpack_detections(packed: Tensor, counts: Tensor) -> List[dict]:
+    """Padded rows + counts (int, or the fp32 counts of ``gather_padded_detections``) -> the per-image dictionaries."""
     out = []
-    for row, c in zip(packed, counts.tolist()):
+    for row, c in zip(packed, (int(v) for v in counts.tolist())):
         out.append({"boxes": row[:c, :4], "scores": row[:c, 4], "labels": row[:c, 5].to(torch.int64)})
     return out
+
+
+def _exchange(local: Tensor, gathered: Optional[Tensor], group) -> Tensor:
+    """All-gather of equally shaped 2-d messages, rank order along dim 0 (``gathered``: optional output buffer)."""
+    world = dist.get_world_size(group)
+    staged = local.is_cuda and dist.get_backend(group) == "gloo"      # gloo exchanges host memory
+    device = local.device
+    if staged:
+        local, gathered = local.cpu(), None
+    if gathered is None:
+        gathered = local.new_empty((world * local.shape[0], local.shape[1]))
+    try:
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    except (RuntimeError, NotImplementedError):   # backends without the flat form
+        parts = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(parts, local, group=group)
+        gathered = torch.cat(parts)
+    return gathered.to(device) if staged else gathered
+
+
+def _distributed(group) -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 def all_gather_detections(packed: Tensor, counts: Tensor, group=None) -> Tuple[Tensor, Tensor]:
@@ -40,25 +63,45 @@ def all_gather_detections(packed: Tensor, counts: Tensor, group=None) -> Tuple[T
 
     All ranks must hold the same ``B_local`` (pad the last shard with count 0 rows otherwise).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _distributed(group):
         return packed, counts
-    world = dist.get_world_size(group)
     B = packed.shape[0]
     # one message per rank: the detections of an image followed by its count (exact in fp32: counts <= D < 2^24)
     local = torch.cat((packed.reshape(B, -1), counts.to(packed.dtype).reshape(B, 1)), dim=1).contiguous()
-    staged = local.is_cuda and dist.get_backend(group) == "gloo"      # gloo exchanges host memory
-    device = local.device
-    if staged:
-        local = local.cpu()
-    gathered = local.new_empty((world * B, local.shape[1]))
-    try:
-        dist.all_gather_into_tensor(gathered, local, group=group)
-    except (RuntimeError, NotImplementedError):   # backends without the flat form
-        parts = [torch.empty_like(local) for _ in range(world)]
-        dist.all_gather(parts, local, group=group)
-        gathered = torch.cat(parts)
-    if staged:
-        gathered = gathered.to(device)
-    g_packed = gathered[:, :-1].reshape((world * B,) + tuple(packed.shape[1:]))
+    gathered = _exchange(local, None, group)
+    g_packed = gathered[:, :-1].reshape((gathered.shape[0],) + tuple(packed.shape[1:]))
     g_counts = gathered[:, -1].to(counts.dtype)
     return g_packed, g_counts
+
+
+_message_buffers: Dict[tuple, Tuple[Tensor, Optional[Tensor]]] = {}
+
+
+def gather_padded_detections(boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tensor, group=None,
+                             reuse_buffers: bool = False) -> Tuple[Tensor, Tensor]:
+    """The inference step's one exchange, from the padded outputs of the NMS: ``boxes [B_local, D, 4]``,
+    ``scores [B_local, D]``, ``labels [B_local, D]`` int64, ``counts [B_local]`` int32 ->
+    ``(packed [R*B_local, D, 6] fp32, counts [R*B_local] fp32)`` over the R ranks, rank order.
+
+    GPU tensors are packed by one kernel (``od_pack_detections``) and exchanged in one collective.  With
+    ``reuse_buffers`` the message and the gathered buffer are kept per stream and overwritten by the next call on the
+    same stream (the results are views of them): for loops that consume the detections before the next step."""
+    if not boxes.is_cuda:                        # host tensors (the gloo tests): same message, built with torch ops
+        g_packed, g_counts = all_gather_detections(pack_detections(boxes, scores, labels), counts, group)
+        return g_packed, g_counts.to(torch.float32)
+    from . import kernels
+    B, D = int(boxes.shape[0]), int(boxes.shape[1])
+    world = dist.get_world_size(group) if _distributed(group) else 1
+    dev = boxes.device
+    key = (dev.index, kernels._raw_stream(dev), B, D, world)
+    bufs = _message_buffers.get(key) if reuse_buffers else None
+    if bufs is None:
+        bufs = (torch.empty((B, 6 * D + 1), dtype=torch.float32, device=dev),
+                torch.empty((world * B, 6 * D + 1), dtype=torch.float32, device=dev) if world > 1 else None)
+        if reuse_buffers:
+            if len(_message_buffers) > 64:
+                _message_buffers.clear()
+            _message_buffers[key] = bufs
+    local = kernels.pack_detections(boxes, scores, labels, counts, out=bufs[0])
+    gathered = _exchange(local, bufs[1], group) if world > 1 else local
+    return gathered[:, :-1].reshape(gathered.shape[0], D, 6), gathered[:, -1]

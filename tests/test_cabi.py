@@ -107,6 +107,12 @@ def test_argument_errors_of_loss_transform_and_planar_entries():
     assert lib.od_select_candidates_planar(*args, None, *tail) == -1                  # plane sizes missing
     assert lib.od_select_candidates_planar(*args, (ctypes.c_int64 * 1)(7), *tail) == -1   # 90 anchors are not a multiple of 7
     assert lib.od_profile_stride(0) == -1 and lib.od_profile_stride(1) == 0
+    # message of the detections all-gather: negative sizes, null pointers, misaligned boxes, empty batch
+    assert lib.od_pack_detections(p16, p16, p16, p16, -1, 10, p16, null) == -1
+    assert lib.od_pack_detections(null, p16, p16, p16, 2, 10, p16, null) == -1
+    assert lib.od_pack_detections(ctypes.c_void_p(20), p16, p16, p16, 2, 10, p16, null) == -1
+    assert lib.od_pack_detections(p16, p16, p16, p16, 70000, 10, p16, null) == -2
+    assert lib.od_pack_detections(null, null, null, null, 0, 10, null, null) == 0
 
 
 def test_no_cpu_fallback():

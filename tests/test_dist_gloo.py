@@ -34,6 +34,11 @@ def _worker(rank, world, port, total, d, ret):
     dets = sharding.unpack_detections(g_packed, g_counts)
     ok = ok and all(dd["boxes"].shape[0] == int(c) for dd, c in zip(dets, counts))
     ok = ok and all(torch.equal(dd["labels"], labels[i, : int(counts[i])]) for i, dd in enumerate(dets))
+    # the one-call route from the padded NMS outputs (host tensors here: same message, built with torch ops)
+    p2, c2 = sharding.gather_padded_detections(boxes[lo:hi], scores[lo:hi], labels[lo:hi].to(torch.int64), counts[lo:hi])
+    ok = ok and torch.equal(p2, full) and torch.equal(c2.to(torch.int32), counts)
+    dets2 = sharding.unpack_detections(p2, c2)
+    ok = ok and all(torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["labels"], b["labels"]) for a, b in zip(dets, dets2))
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -547,3 +547,30 @@ def test_select_sampled_bound_large_levels(device):
     fc = torch.empty((2, Nf, 1)).normal_(0.0, 1.0, generator=gen)
     _check_select_single_level(device, fl, Cf, 0.2, 1000, ctrness=fc)
     _check_select_single_level(device, fl, Cf, 0.6, 300, ctrness=fc)
+
+
+@pytest.mark.parametrize("batch,max_det", [(1, 1), (3, 300), (16, 500), (2, 257)])
+def test_pack_detections_is_the_gather_message(device, batch, max_det):
+    """od_pack_detections writes, bit for bit, the message the host-side packing builds (rows x1,y1,x2,y2,score,label,
+    then the count), and the one-call gather route returns it unchanged when no process group exists."""
+    from object_detection_amd import sharding
+    gen = torch.Generator().manual_seed(7 * batch + max_det)
+    boxes = torch.rand((batch, max_det, 4), generator=gen) * 1024
+    scores = torch.rand((batch, max_det), generator=gen)
+    labels = torch.randint(0, 1 << 24, (batch, max_det), generator=gen)
+    counts = torch.randint(0, max_det + 1, (batch,), generator=gen, dtype=torch.int32)
+    ref = torch.cat((sharding.pack_detections(boxes, scores, labels).reshape(batch, -1),
+                     counts.to(torch.float32).reshape(batch, 1)), dim=1)
+    dev = [t.to(device) for t in (boxes, scores, labels, counts)]
+    msg = kernels.pack_detections(*dev)
+    assert msg.shape == (batch, 6 * max_det + 1) and torch.equal(msg.cpu(), ref)
+    for reuse in (False, True, True):
+        packed, cnt = sharding.gather_padded_detections(*dev, reuse_buffers=reuse)
+        assert torch.equal(packed.cpu(), ref[:, :-1].reshape(batch, max_det, 6))
+        assert torch.equal(cnt.cpu().to(torch.int32), counts)
+    dets = sharding.unpack_detections(packed, cnt)
+    assert all(torch.equal(d["labels"].cpu(), labels[i, :int(counts[i])]) for i, d in enumerate(dets))
+    with pytest.raises(TypeError):
+        kernels.pack_detections(dev[0], dev[1], dev[2].to(torch.int32), dev[3])
+    with pytest.raises(ValueError):
+        kernels.pack_detections(dev[0], dev[1][:, :-1] if max_det > 1 else dev[1][:0], dev[2], dev[3])
