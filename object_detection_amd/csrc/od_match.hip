@@ -55,9 +55,7 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
     int argmax16;
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
     uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT (index into the batch's GT list), y = value key (tile maximum)
-    int* image_flag;             // [batch]            1 = some GT of the image has maximum IoU 0
     unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
-    int* any_flag;               // [1]                some image_flag is set
     int4* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot, GT met, -) for the cooperative kernel
     uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT (as above), z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
@@ -369,25 +367,6 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
     }
 }
 
-// image_flag[b] = 1 if some GT row of image b has maximum IoU exactly 0 (one wave per image)
-__global__ __launch_bounds__(64) void match_flag_kernel(const int* __restrict__ gt_offsets, MatchWs ws) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const int m0 = gt_offsets[b], M = gt_offsets[b + 1] - m0;
-    bool any0 = false;
-    for (int g0 = 0; g0 < M; g0 += 256) {
-        uint32_t k[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int g = g0 + u * 64 + lane; k[u] = g < M ? ws.gt_max_key[(long long)(m0 + g) * GSTRIDE] : 0xffffffffu; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) any0 = any0 || (ordered_key_inv(k[u]) == 0.0f);
-    }
-    const unsigned long long m = __ballot(any0);
-    if (lane == 0) {
-        ws.image_flag[b] = m ? 1 : 0;
-        if (m) *ws.any_flag = 1;                     // some image restores every anchor
-    }
-}
-
 // Wave-cooperative re-examination of one tile against the GT range [g_begin, g_end) of its image: the IoUs
 // are recomputed with the same code as in the assign kernel (bit-identical values) and every anchor that
 // attains a GT's global maximum is restored.  All 64 lanes must call it with wave-uniform arguments.
@@ -477,20 +456,36 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
 }
 
 // Restore from the entries.  Blocks [0, light_blocks) take the light tiles, one thread per (entry slot,
-// tile); the remaining blocks take the heavy tiles' entries, one thread per entry.  For an entry whose value
-// equals its GT's global maximum the wave re-examines that row segment (restore_row_segment).  Last, images
-// whose flag is set restore every anchor.  If the heavy-entry buffer was too small (pathological inputs) the
-// heavy blocks re-examine every heavy tile against all GT of its image instead.
+// tile); the next heavy_blocks blocks take the heavy tiles' entries, one thread per entry.  For an entry whose
+// value equals its GT's global maximum the wave re-examines that row segment (restore_row_segments).  If the
+// heavy-entry buffer was too small (pathological inputs) the heavy blocks re-examine every heavy tile against all
+// GT of its image instead.  The last ZB blocks per image look for a GT row whose maximum IoU is exactly 0: every
+// anchor attains that maximum, so the image restores every anchor (torchvision's behaviour when a GT overlaps no
+// anchor); the values written are the ones the entry blocks write, so the order between the blocks is irrelevant.
+constexpr int ZB = 8;
 __global__ __launch_bounds__(256) void match_restore_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int batch,
-    int light_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
+    int light_blocks, int heavy_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
     long long* __restrict__ matched) {
     const long long total = (long long)batch * wtiles;
     const int lane = threadIdx.x & 63;
     const bool light = (int)blockIdx.x < light_blocks;
     // light blocks share one index space; heavy blocks are dealt round-robin to the images
     const int hb = (int)blockIdx.x - light_blocks;
-    const int hblocks = ((int)gridDim.x - light_blocks) / batch;        // heavy blocks per image
+    if (!light && hb >= heavy_blocks) {                                  // zero-maximum blocks
+        const int zb = hb - heavy_blocks;
+        const int b = zb / ZB, part = zb - b * ZB;
+        if (b >= batch) return;
+        const int m0 = gt_offsets[b], M = gt_offsets[b + 1] - m0;
+        int any0 = 0;
+        for (int g = threadIdx.x; g < M; g += 256)
+            any0 |= (ordered_key_inv(ws.gt_max_key[(long long)(m0 + g) * GSTRIDE]) == 0.0f) ? 1 : 0;
+        if (!__syncthreads_or(any0)) return;
+        for (long long idx = (long long)part * 256 + threadIdx.x; idx < n; idx += ZB * 256)
+            matched[(long long)b * n + idx] = (long long)get_argmax(ws, (long long)b * n + idx);
+        return;
+    }
+    const int hblocks = heavy_blocks / batch;                            // heavy blocks per image
     const int hb_image = light ? 0 : hb % batch;
     const long long nthreads = (long long)(light ? light_blocks : hblocks) * 256;
     const long long first = (long long)(light ? (int)blockIdx.x : hb / batch) * 256 + (threadIdx.x & ~63);
@@ -528,8 +523,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
         }
         bool hit = false;
         if (have && key > kZeroKey) {
-            const int b = wslot / wtiles;
-            hit = key == ws.gt_max_key[(long long)word * GSTRIDE] && !ws.image_flag[b];
+            hit = key == ws.gt_max_key[(long long)word * GSTRIDE];
         }
         unsigned long long hits = __ballot(hit);         // the loop bounds are wave-uniform: all lanes are here
         while (hits) {
@@ -549,7 +543,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
             restore_row_segments(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, hs, hg, hk, matched);
         }
     }
-    if (overflow && hb / batch < hblocks && !ws.image_flag[hb_image]) {   // one wave per (heavy tile, 64-GT chunk)
+    if (overflow && hb / batch < hblocks) {   // one wave per (heavy tile, 64-GT chunk)
         const int chunks = (gt_offsets[hb_image + 1] - gt_offsets[hb_image] + 63) >> 6;
         const long long items = (long long)nheavy * chunks;
         for (long long q = first >> 6; q < items; q += nthreads >> 6) {
@@ -558,13 +552,6 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
             recheck_segment(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, wslot, (int)(q - h * chunks) * 64,
                             64, matched);
         }
-    }
-    if (*ws.any_flag == 0) return;                       // no image restores every anchor (the usual case)
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long all_threads = (long long)gridDim.x * 256;
-    for (int b = 0; b < batch; ++b) {
-        if (!ws.image_flag[b] || gt_offsets[b + 1] - gt_offsets[b] <= 0) continue;
-        for (long long idx = tid; idx < n; idx += all_threads) matched[(long long)b * n + idx] = (long long)get_argmax(ws, (long long)b * n + idx);
     }
 }
 
@@ -677,8 +664,8 @@ static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t of
     off[1] = off[0] + align256((size_t)(m_total > 0 ? m_total : 0) * GSTRIDE * sizeof(uint32_t));   // argmax
     off[2] = off[1] + align256((size_t)batch * (size_t)n * sizeof(int));            // wave_cnt
     off[3] = off[2] + align256(tiles * sizeof(int));                                // wave_list
-    off[4] = off[3] + align256(tiles * LCAP * sizeof(uint2));                       // image_flag
-    off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // any_flag (256 B) + heavy_count
+    off[4] = off[3] + align256(tiles * LCAP * sizeof(uint2));                       // (reserved)
+    off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // 256 B reserved, then heavy_count
     off[6] = off[5] + 256 + (size_t)batch * 128;                                    // heavy_queue
     off[7] = off[6] + align256(tiles * sizeof(int4));                               // heavy_entries
     off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));     // end
@@ -716,8 +703,6 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     ws.argmax16 = m_total <= 65536 ? 1 : 0;
     ws.wave_cnt = (int*)(w + off[2]);
     ws.wave_list = (uint2*)(w + off[3]);
-    ws.image_flag = (int*)(w + off[4]);
-    ws.any_flag = (int*)(w + off[5]);
     ws.heavy_count = (unsigned long long*)(w + off[5] + 256);
     ws.heavy_queue = (int4*)(w + off[6]);
     ws.heavy_entries = (uint4*)(w + off[7]);
@@ -725,7 +710,7 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
     dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
     if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total * GSTRIDE, s));
-    OD_HIP(hipMemsetAsync(ws.any_flag, 0, 256 + (size_t)batch * 128, s));
+    OD_HIP(hipMemsetAsync(ws.heavy_count, 0, (size_t)batch * 128, s));
     const long long stride = (long long)anchor_batch_stride;
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
                      (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
@@ -738,15 +723,13 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
-        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FLAG, match_flag_kernel, dim3((unsigned)batch), dim3(64), 0, s, gt_offsets,
-                         ws);
         const long long light_threads = total_tiles * LCAP;
         const int light_blocks = (int)((light_threads + 255) / 256 < 8192 ? (light_threads + 255) / 256 : 8192);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
-                         dim3((unsigned)(light_blocks + heavy_entry_blocks)), dim3(256), 0, s, (const float4*)anchors,
-                         stride, (long long)n, wtiles, (int)batch, light_blocks, (const float4*)gt_boxes, gt_offsets, ws,
-                         (long long*)matched);
+                         dim3((unsigned)(light_blocks + heavy_entry_blocks + batch * ZB)), dim3(256), 0, s,
+                         (const float4*)anchors, stride, (long long)n, wtiles, (int)batch, light_blocks,
+                         heavy_entry_blocks, (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
     }
     return OD_OK;
 }

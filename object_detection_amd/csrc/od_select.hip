@@ -338,12 +338,15 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {        // monotone m
 }
 __device__ __forceinline__ float from_ordered_bits(uint32_t k) { return u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
 
-__global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* __restrict__ cuts) {
+__global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* __restrict__ cuts,
+                                                       unsigned int* __restrict__ counters, long long counter_words) {
     __shared__ unsigned int s_hist[HBINS];
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y;
     const long long E = p.level_elems[l];
+    // this (image, level)'s three key counters start at zero (the filter launches that follow add to them)
+    if (tid < 3) counters[tid * counter_words + ((long long)b * p.num_levels + l) * CSTRIDE] = 0u;
     CutInfo out;
     out.cut = 0.0f; out.pre = p.pre_logit; out.active = 0; out.pad = 0;
     if (E < SAMPLE_MIN) {
@@ -838,11 +841,10 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
     sp.coder = coder;
     sp.clip = bbox_xform_clip;
 
-    OD_HIP(hipMemsetAsync(key_count, 0, 3 * lay.counter_bytes, s));
     bool sampled = false;                          // does any level get a sampled cut?
     for (int l = 0; l < num_levels; ++l) sampled = sampled || fp.level_elems[l] >= SAMPLE_MIN;
     OD_LAUNCH_KERNEL(OD_KERNEL_SAMPLE, sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,
-                     fp, cuts);
+                     fp, cuts, key_count, (long long)(lay.counter_bytes / 4));
     if (lay.total_chunks > 0) {
         const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
         OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,

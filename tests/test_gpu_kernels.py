@@ -58,6 +58,17 @@ def test_match_retinanet_gt_without_overlap(device):
     ref = tv.retinanet_match([gt], [anchors], 0.6, 0.5)[0]
     assert torch.equal(out, ref)
     assert (out >= 0).all()
+    # in a batch: only the image that holds such a GT restores every anchor; with enough GT for the coarse tiles to
+    # take the cooperative kernel, and an image without GT
+    ag, anchors = _anchors_cpu((512, 512), (64, 32, 16, 8, 4), synthetic.retinanet_anchor_sizes(5, 32))
+    gts = [synthetic.make_gt_boxes(60, (512, 512), torch.Generator().manual_seed(s)) for s in (1, 2, 3)]
+    gts[1] = torch.cat((gts[1][:30], torch.tensor([[9000., 9000., 9010., 9020.]]), gts[1][30:]))
+    gts.append(torch.zeros((0, 4)))
+    out = kernels.match_retinanet(anchors.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+    ref = tv.retinanet_match(gts, [anchors] * len(gts), 0.6, 0.5)
+    for b in range(len(gts)):
+        assert torch.equal(out[b], ref[b]), f"image {b}"
+    assert (out[1] >= 0).all() and (out[0] < 0).any() and (out[2] < 0).any() and (out[3] == -1).all()
 
 
 def test_match_retinanet_kat(device):
