@@ -36,6 +36,7 @@ from object_detection_amd import _C, kernels, sharding, synthetic  # noqa: E402
 from object_detection_amd.retinanet_model import get_model  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+NUM_CUS = 256            # compute units of one MI355X
 # HBM bytes per launch from the rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE; collected by tools/pmc_bench.sh in
 # separate profiler runs of this same script and committed): PMC counters cannot be read from inside the process.
 PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
@@ -119,7 +120,7 @@ def cpu_baseline(cfg, sample_images: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--cpu-sample", type=int, default=48,
                     help="images in the CPU-baseline sample (0 = skip); 48 = three batches, 10-15 s of CPU work")
@@ -280,7 +281,15 @@ def main():
         if n:
             probe[name] = {"ms_per_launch": ms / n, "launches_per_step": n / 3}
     n_cand = float(kernels_candidates_per_image(cfg, split, split_anchors, shapes, model))
-    dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"])
+    # Dominant = the kernel that occupies most of the chip per step: duration x the share of the 256 CUs its grid can
+    # fill.  NMS (one workgroup per image) and the top-k kernels (one per image and level) are as long as the matching
+    # kernel but hold 16 / 96 CUs while the rest of the chip runs other streams' kernels; a chip-level roofline says
+    # nothing about them (their own bound is the latency of one workgroup).
+    narrow = {"nms": cfg.batch, "select": cfg.batch * L, "sample": cfg.batch * L}
+    for name, pr in probe.items():
+        pr["cu_share"] = min(1.0, narrow.get(name, NUM_CUS) / NUM_CUS)
+    dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"]
+                   * probe[name]["cu_share"])
     dom_id = _C.KERNEL_NAMES.index(dominant)
     # In the timed region every 8th launch of the dominant kernel is timed (start / stop events on the dispatch):
     # a timed launch costs the host tens of microseconds, which would otherwise end up in `value`.
@@ -385,6 +394,7 @@ def main():
             },
             "roofline": {
                 "kernel": dominant,
+                "dominant_by": "duration x share of the 256 CUs the grid can fill (kernels[*].cu_share)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
