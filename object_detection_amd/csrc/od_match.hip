@@ -25,7 +25,7 @@
 //   tiles that tie for a GT's maximum) a wave recomputes that (tile, GT) row segment with the same IoU code (hence
 //   bit-identical values) and patches `matched` from the stored argmax for every anchor attaining it.
 //   If some GT has maximum 0 (it overlaps no anchor) every anchor ties at 0 for that row and torchvision
-//   restores ALL anchors; a flag per image reproduces that.
+//   restores ALL anchors; a few blocks of the restore kernel look for such rows and do that.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -47,6 +47,9 @@ constexpr int HT = OD_HT;        // threads of the cooperative (heavy tile) work
 #endif
 constexpr int GSTRIDE = OD_GSTRIDE;   // words between two GT maxima: atomics on one 128-byte line serialise
 constexpr int HCAP_PER_GT = 160;  // heavy-entry buffer capacity = HCAP_PER_GT * m_total + 4096
+constexpr int COUNT_ALL = 512;    // images with more GT stop counting a tile's GT as soon as the tile is known to be heavy
+constexpr int GMAX_LDS = 4096;    // GT per image up to which the cooperative kernel accumulates the row maxima in LDS
+constexpr int ECAP = 128;         // entries a wave of the cooperative kernel stages in LDS between two flushes
 
 struct MatchWs {                 // workspace carve-up (all device pointers)
     uint32_t* gt_max_key;        // [m_total * GSTRIDE] ordered-key maximum IoU of every GT row, one per GSTRIDE words
@@ -56,7 +59,7 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
     int* wave_cnt;               // [batch * wtiles]   entries of a light tile, -2 = heavy tile
     uint2* wave_list;            // [LCAP, batch * wtiles] entry-major: x = GT (index into the batch's GT list), y = value key (tile maximum)
     unsigned long long* heavy_count;   // [batch * 16]   per image (128 B apart): heavy tiles << 32 | heavy entries
-    int4* heavy_queue;           // [batch, wtiles]    (tile of the image, first entry slot, GT met, -) for the cooperative kernel
+    int4* heavy_queue;           // [batch, wtiles]    (tile of the image, -, GT met (a lower bound beyond COUNT_ALL GT), -) for the cooperative kernel
     uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT (as above), z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
     long long list_stride;       // batch * wtiles
@@ -217,13 +220,13 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
                 bool ok = g < M;
                 if (ok) ok = overlaps_tile(t, gt[m0 + g]);
                 cnt += __popcll(__ballot(ok));
+                if (M > COUNT_ALL && cnt > HEAVY) break;      // wave-uniform; dense images: every tile is heavy
             }
         }
         if (cnt > HEAVY) {
-            if (lane == 0) {                       // queue slot + room for one entry per GT met, in one atomic
-                const unsigned long long old =
-                    atomicAdd(ws.heavy_count + b * 16, (1ull << 32) | (unsigned long long)(want_restore ? cnt : 0));
-                ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int4(wt, (int)(uint32_t)old, cnt, 0);
+            if (lane == 0) {                       // queue slot (the cooperative kernel reserves its entries itself)
+                const unsigned long long old = atomicAdd(ws.heavy_count + b * 16, 1ull << 32);
+                ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int4(wt, 0, cnt, 0);
                 if (want_restore) ws.wave_cnt[wslot] = -2;
             }
             return;
@@ -275,9 +278,15 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
 // Cooperative kernel for the queued heavy tiles: one workgroup of NW waves per tile.  The waves share
 // the tile's 256 anchors, every wave scans all GT but scores only every NW-th survivor; per-anchor
 // (max, first argmax) are merged through LDS (equal maxima -> smaller GT index, which is the first maximal
-// index of the full row).  The entry of the survivor with rank r goes to slot r of the region the assign
-// kernel reserved for the tile, so the kernel needs no atomics besides the per-GT maxima.
-__global__ __launch_bounds__(HT) void match_heavy_kernel(
+// index of the full row).
+// Nothing inside the GT loop goes to global memory: a store or an atomic issued between two chunks would have
+// to complete before the next chunk's prefetched boxes can be used (the number of younger operations is not
+// known at compile time, so the wait is for all of them), one memory round trip per 64 GT -- with 2000 GT per
+// image that was 2.4 times the kernel's arithmetic.  Entries (GT, tile maximum) are staged per wave in LDS and
+// written ECAP at a time to slots reserved with one atomic per flush; row maxima are accumulated with LDS
+// atomics and merged into the global maxima once per tile (images with more than GMAX_LDS GT keep the
+// per-chunk global atomics).
+__global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void match_heavy_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles,
     const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
     float high, float low, long long* __restrict__ matched) {
@@ -286,13 +295,20 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
     __shared__ int s_bidx[NW][WTILE];
     __shared__ int s_cost[HT];
     __shared__ int s_pick;
+    __shared__ uint32_t s_gmax[GMAX_LDS];          // row maxima of the current tile (ordered keys; 0 = no overlap)
+    __shared__ uint2 s_ent[NW][ECAP];              // staged entries of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
     const unsigned long long hc = ws.heavy_count[b * 16];
     const int nheavy = (int)(hc >> 32);
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
-    const bool entries_fit = (long long)(uint32_t)hc <= entry_cap(M);   // else the restore kernel redoes the image's heavy tiles
+    const bool lds_max = want_restore && M <= GMAX_LDS;
+    const long long ebase = entry_base(b, m0), ecap = entry_cap(M);
+    if (lds_max) {
+        for (int g = threadIdx.x; g < M; g += HT) s_gmax[g] = 0u;
+        __syncthreads();
+    }
     // Blocks are numbered image-fastest, so the hardware hands out "the r-th tile of every image" together.
     // With r = rank by cost (GT met, descending) every CU receives a mix of expensive and cheap tiles
     // instead of whatever the arrival order of the queue gives; done when the queue fits one pass.
@@ -319,8 +335,6 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
         const int4 qi = ws.heavy_queue[(long long)b * wtiles + pick];
         const int wt = qi.x;
         const long long wslot = (long long)b * wtiles + wt;
-        const long long ebase = entry_base(b, m0) + qi.y;
-        uint4* entries = ws.heavy_entries + ebase;
         const long long base = (long long)wt * WTILE;
         long long* out = matched + (long long)b * n;
         WaveTile t;
@@ -330,24 +344,57 @@ __global__ __launch_bounds__(HT) void match_heavy_kernel(
 #pragma unroll
         for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; }
         uint32_t kreg = 0u;
-        for_each_overlapping_gt(t, gt, m0, want_restore ? ws.gt_max_key : nullptr, 0, M, wave, NW,
-            [&](int g, int j, int rank, float gx1, float gy1, float gx2, float gy2, float ga) {
+        int staged = 0;                               // wave-uniform: entries of this wave waiting in s_ent[wave]
+        // slots of the image's entry region for the staged entries (one returning atomic per flush); if the region
+        // is full nothing is written and the total, which still counts them, tells the restore kernel so
+        auto flush_entries = [&]() {
+            if (staged == 0) return;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // lane 0 wrote the entries, all lanes read them
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned long long old = 0ull;
+            if (lane == 0) old = atomicAdd(ws.heavy_count + b * 16, (unsigned long long)staged);
+            const long long at = (long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)old);
+            if (at + staged <= ecap) {
+                for (int i = lane; i < staged; i += 64) {
+                    const uint2 e = s_ent[wave][i];
+                    ws.heavy_entries[ebase + at + i] = make_uint4((uint32_t)wslot, e.x, e.y, 0u);
+                }
+            }
+            staged = 0;
+        };
+        for_each_overlapping_gt(t, gt, m0, (want_restore && !lds_max) ? ws.gt_max_key : nullptr, 0, M, wave, NW,
+            [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
                 const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
-                if (want_restore) {
+                if (want_restore && k > kZeroKey) {    // wave-uniform: this GT overlaps an anchor of the tile
                     kreg = (lane == j) ? k : kreg;
-                    // every survivor's slot is written: key 0 (never a maximum) marks "no overlapping anchor"
-                    if (entries_fit && lane == 0)
-                        entries[rank] = make_uint4((uint32_t)wslot, (uint32_t)(m0 + g), k == kZeroKey ? 0u : k, 0u);
+                    if (lane == 0) s_ent[wave][staged] = make_uint2((uint32_t)(m0 + g), k);
+                    if (++staged == ECAP) flush_entries();
                 }
             },
             [&](int g0, uint32_t cur) {
                 if (!want_restore) return;
-                if (kreg > cur) atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
+                if (lds_max) {
+                    if (kreg > kZeroKey) atomicMax(&s_gmax[g0 + lane], kreg);
+                } else if (kreg > cur) {
+                    atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
+                }
                 kreg = 0u;
             });
+        flush_entries();
 #pragma unroll
         for (int r = 0; r < R; ++r) { s_best[wave][r * 64 + lane] = best[r]; s_bidx[wave][r * 64 + lane] = bidx[r]; }
         __syncthreads();
+        if (lds_max) {                                // merge the tile's row maxima into the global ones
+            for (int g = threadIdx.x; g < M; g += HT) {
+                const uint32_t v = s_gmax[g];
+                if (v > kZeroKey) {
+                    s_gmax[g] = 0u;                   // ready for the next tile
+                    uint32_t* gm = &ws.gt_max_key[(long long)(m0 + g) * GSTRIDE];
+                    if (v > *gm) atomicMax(gm, v);
+                }
+            }
+        }
         if (threadIdx.x < WTILE) {
             float bb = s_best[0][threadIdx.x];
             int bi = s_bidx[0][threadIdx.x];
