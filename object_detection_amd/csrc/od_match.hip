@@ -602,8 +602,20 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     }
 }
 
-// ---- FCOS centre sampling: one thread per anchor, GT staged in LDS --------------------------------
+// ---- FCOS centre sampling: 64 anchors per workgroup, GT staged in LDS ---------------------------------
+// A GT can match an anchor only if the anchor's centre lies within radius * size of the GT's centre.  The four
+// waves of a workgroup share 64 consecutive anchors (a piece of a row of one pyramid level, mostly; one per lane)
+// and split the GT list in interleaved runs of 64.  A wave keeps the bounding box of the anchors' centres and
+// their largest sampling radius, tests 64 GT at a time against that box (one per lane, with a margin that covers
+// the rounding of the two formulations) and evaluates only the survivors, in ascending order, with all lanes;
+// the four partial (maximum, first index) pairs are merged through LDS.  On the coarse levels, where every GT
+// survives, the split shortens the serial loop that bounds the kernel.
+// A GT that is skipped has value 0 * (1e8 - area) = +0 for every anchor and can never win the strict '>' of the
+// argmax, and the split keeps "first index of the maximum" -- provided every value is >= +0, i.e. every GT area is
+// finite and below 1e8.  An image whose GT list holds any other box is evaluated by one wave, every GT in list
+// order, exactly as the sequential formulation (GT 0 initialises the running maximum, as torch's argmax does).
 constexpr int FT = 256;
+constexpr int FW = FT / 64;      // waves per workgroup = ways the GT list is split
 constexpr int FGCH = 1024;
 
 __global__ __launch_bounds__(FT) void match_fcos_kernel(
@@ -611,40 +623,98 @@ __global__ __launch_bounds__(FT) void match_fcos_kernel(
     long long n_last, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, float radius,
     long long* __restrict__ matched) {
     __shared__ float4 s_g[FGCH];
+    __shared__ float s_best[FW][64];
+    __shared__ int s_bi[FW][64];
     const int b = blockIdx.y;
-    const long long idx = (long long)blockIdx.x * FT + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + lane;
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     const bool valid = idx < n;
-    float4 a = make_float4(0.f, 0.f, 1.f, 1.f);
-    if (valid) a = anchors[(long long)b * anchor_batch_stride + idx];
+    // lanes past the end replay the last anchor (their result is not written)
+    const float4 a = anchors[(long long)b * anchor_batch_stride + (valid ? idx : n - 1)];
     // anchor_centers = (a[:, :2] + a[:, 2:]) / 2 ; anchor_sizes = a[:, 2] - a[:, 0]
     const float cx = (a.x + a.z) / 2.0f, cy = (a.y + a.w) / 2.0f;
     const float size = a.z - a.x;
     const float lower = (idx < n_first) ? 0.0f : size * 4.0f;
     const float upper = (idx >= n - n_last) ? __builtin_inff() : size * 8.0f;
     const float rs = radius * size;
+    // the wave's box of centres, widened by the largest radius and a rounding margin
+    const float cx_lo = wave_fmin_all(cx), cx_hi = wave_fmax_all(cx);
+    const float cy_lo = wave_fmin_all(cy), cy_hi = wave_fmax_all(cy);
+    const float rs_max = wave_fmax_all(rs);
+    const float pad = rs_max + 1e-3f * (rs_max + fmaxf(fabsf(cx_lo), fabsf(cx_hi)) + fmaxf(fabsf(cy_lo), fabsf(cy_hi)) + 1.0f);
+    const float x_lo = cx_lo - pad, x_hi = cx_hi + pad, y_lo = cy_lo - pad, y_hi = cy_hi + pad;
+
+    // one pass over the image's GT list: is every value >= +0 ?  The first FGCH boxes are staged on the way.
+    int plain_here = 1;
+    for (int g = threadIdx.x; g < M; g += FT) {
+        const float4 G = gt[m0 + g];
+        if (g < FGCH) s_g[g] = G;
+        const float garea = (G.z - G.x) * (G.w - G.y);
+        plain_here &= (garea < 1e8f && garea > -__builtin_inff()) ? 1 : 0;         // false for NaN as well
+    }
+    const bool plain = __syncthreads_and(plain_here) != 0;
+
     float best = 0.0f;
-    int bi = 0;
+    int bi = plain ? 0x7fffffff : 0;
+    auto evaluate = [&](const float4 G) {
+        float gcx = (G.x + G.z) / 2.0f, gcy = (G.y + G.w) / 2.0f;
+        float dmax = fmaxf(fabsf(cx - gcx), fabsf(cy - gcy));
+        float l = cx - G.x, t = cy - G.y, r = G.z - cx, bt = G.w - cy;
+        float mn = fminf(fminf(l, t), fminf(r, bt));
+        float mx = fmaxf(fmaxf(l, t), fmaxf(r, bt));
+        bool match = (dmax < rs) && (mn > 0.0f) && (mx > lower) && (mx < upper);
+        float garea = (G.z - G.x) * (G.w - G.y);
+        return (match ? 1.0f : 0.0f) * (1e8f - garea);
+    };
     for (int c0 = 0; c0 < M; c0 += FGCH) {
-        __syncthreads();
-        for (int g = threadIdx.x; g < FGCH && c0 + g < M; g += FT) s_g[g] = gt[m0 + c0 + g];
-        __syncthreads();
+        if (c0 > 0) {                                      // the first chunk is staged already
+            __syncthreads();
+            for (int g = threadIdx.x; g < FGCH && c0 + g < M; g += FT) s_g[g] = gt[m0 + c0 + g];
+            __syncthreads();
+        }
         const int cnt = min(FGCH, M - c0);
-        for (int j = 0; j < cnt; ++j) {
-            const float4 G = s_g[j];
-            float gcx = (G.x + G.z) / 2.0f, gcy = (G.y + G.w) / 2.0f;
-            float dmax = fmaxf(fabsf(cx - gcx), fabsf(cy - gcy));
-            float l = cx - G.x, t = cy - G.y, r = G.z - cx, bt = G.w - cy;
-            float mn = fminf(fminf(l, t), fminf(r, bt));
-            float mx = fmaxf(fmaxf(l, t), fmaxf(r, bt));
-            bool match = (dmax < rs) && (mn > 0.0f) && (mx > lower) && (mx < upper);
-            float garea = (G.z - G.x) * (G.w - G.y);
-            float v = (match ? 1.0f : 0.0f) * (1e8f - garea);
-            if ((c0 + j == 0) || v > best) { best = v; bi = c0 + j; }
+        if (!plain) {
+            if (wave == 0) {                               // sequential formulation, every GT in list order
+                for (int j = 0; j < cnt; ++j) {
+                    const float v = evaluate(s_g[j]);
+                    if ((c0 + j == 0) || v > best) { best = v; bi = c0 + j; }
+                }
+            }
+            continue;
+        }
+        for (int j0 = wave * 64; j0 < cnt; j0 += FW * 64) {
+            const int jl = j0 + lane;
+            bool pass = false;
+            if (jl < cnt) {
+                const float4 G = s_g[jl];
+                const float gcx = (G.x + G.z) / 2.0f, gcy = (G.y + G.w) / 2.0f;
+                // written so that a NaN on either side (an anchor or a GT without a finite centre) keeps the GT
+                pass = !(gcx <= x_lo) && !(gcx >= x_hi) && !(gcy <= y_lo) && !(gcy >= y_hi);
+            }
+            unsigned long long mask = __ballot(pass);
+            while (mask) {                                 // wave-uniform loop, ascending GT index
+                const int j = j0 + __ffsll(mask) - 1;
+                mask &= mask - 1;
+                const float v = evaluate(s_g[j]);
+                if (v > best) { best = v; bi = c0 + j; }
+            }
         }
     }
-    if (valid) matched[(long long)b * n + idx] = (M <= 0 || best < 1e-5f) ? -1 : (long long)bi;
+    s_best[wave][lane] = best;
+    s_bi[wave][lane] = bi;
+    __syncthreads();
+    if (wave != 0 || !valid) return;
+    if (plain) {
+#pragma unroll
+        for (int w = 1; w < FW; ++w) {
+            const float ob = s_best[w][lane];
+            const int oi = s_bi[w][lane];
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+    }
+    matched[(long long)b * n + idx] = (M <= 0 || best < 1e-5f) ? -1 : (long long)bi;
 }
 
 // ---- explicit IoU matrix and Matcher on a given matrix -------------------------------------------
@@ -790,8 +860,8 @@ extern "C" int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, 
     if (anchor_batch_stride != 0 && anchor_batch_stride < n) return OD_ERR_ARG;
     if (((uintptr_t)anchors & 15) || ((uintptr_t)gt_boxes & 15)) return OD_ERR_ARG;
     if (n_first_level < 0 || n_last_level < 0 || n_first_level > n || n_last_level > n) return OD_ERR_ARG;
-    if (batch > 65535) return OD_ERR_LIMIT;
-    dim3 grid((unsigned)((n + FT - 1) / FT), (unsigned)batch);
+    if (batch > 65535 || (n + 63) / 64 > 0x7fffffffll) return OD_ERR_LIMIT;
+    dim3 grid((unsigned)((n + 63) / 64), (unsigned)batch);
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FCOS, match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream,
                      (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
                      (long long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius,

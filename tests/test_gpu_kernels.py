@@ -93,7 +93,7 @@ def test_matcher_matrix_random(device):
     assert torch.equal(kernels.box_iou(a.to(device), b.to(device)).cpu(), tv.box_iou(a, b))
 
 
-@pytest.mark.parametrize("m", [1, 33, 200])
+@pytest.mark.parametrize("m", [1, 33, 200, 1500])
 def test_match_fcos(device, m):
     grids = (64, 32, 16, 8, 4)
     ag, anchors = _anchors_cpu((512, 512), grids, ((8,), (16,), (32,), (64,), (128,)), (1.0,))
@@ -106,6 +106,13 @@ def test_match_fcos(device, m):
         assert torch.equal(out[b], ref[b]), f"image {b}"
         assert np.array_equal(out[b].numpy(), c_oracle.match_fcos(gts[b].numpy(), anchors.numpy(), npl[0], npl[-1], 1.5))
     assert (out[0] >= 0).any()
+    # a box whose area exceeds 1e8 turns the value of a match negative (1e8 - area) and that of a miss into -0.0:
+    # first and in the middle of the list
+    huge = torch.tensor([[-9744., -9744., 10256., 10256.]])
+    for pos in (0, min(3, m)):
+        g = torch.cat((gts[0][:pos], huge, gts[0][pos:]))
+        out = kernels.match_fcos(anchors.to(device), [g.to(device)], npl[0], npl[-1], 1.5).cpu()
+        assert torch.equal(out[0], tv.fcos_match([g], [anchors], npl, 1.5)[0]), f"huge box at {pos}"
 
 
 def test_decode_boxes(device):
