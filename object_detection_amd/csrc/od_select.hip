@@ -33,6 +33,10 @@ constexpr int CAP = 8192;          // keys held in LDS by the select kernel
 constexpr int HBITS = 12;
 constexpr int HBINS = 1 << HBITS;  // histogram bins per radix level
 constexpr int CSTRIDE = 64;        // one key counter per 256 bytes: atomics on one cache line serialise
+#ifndef OD_SAMPLE_MAX
+#define OD_SAMPLE_MAX 131072
+#endif
+constexpr long long SAMPLE_MAX = OD_SAMPLE_MAX;   // largest sample of a level
 constexpr long long SAMPLE_MIN = 262144;   // levels with at least this many logits get a sampled score cut
 constexpr int SAMPLE_RUN = 16;     // consecutive logits per sample position (one 64-byte sector)
 
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
         return;
     }
     long long S = (E / 64) & ~16383ll;
-    S = S < 16384 ? 16384 : (S > 262144 ? 262144 : S);
+    S = S < 16384 ? 16384 : (S > SAMPLE_MAX ? SAMPLE_MAX : S);
     const long long runs = S / SAMPLE_RUN;
     const long long window = E / runs;                         // >= 512 logits
     const long long r64 = (3ll * p.topk * S + E - 1) / E + 32;

@@ -511,7 +511,7 @@ def test_preprocess_images_matches_torch_transform(device, min_size, max_size, s
 def _sampled_positions(E):
     """Positions the candidate selection samples in a level of E logits (E >= 262144): the library's rule restated."""
     S = (E // 64) & ~16383
-    S = min(max(S, 16384), 262144)
+    S = min(max(S, 16384), 131072)
     runs = S // 16
     window = E // runs
     run = np.arange(runs, dtype=np.uint64)

@@ -15,6 +15,8 @@ from tools.microbench import timed  # noqa: E402
 
 
 def main():
+    if os.environ.get("OD_LIB"):                       # experimental build of the library
+        _C.LIB_PATH = os.path.abspath(os.environ["OD_LIB"])
     dev = torch.device("cuda:0")
     cfg = dataclasses.replace(synthetic.CFG4, batch=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     sizes = synthetic.level_sizes(cfg)
