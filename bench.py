@@ -61,7 +61,7 @@ def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
         "select": 12.0 * B * L * K + 48.0 * B * L * K,   # candidate keys + (reg, anchor, box out)
         "match_assign": B * (16.0 * N + 16.0 * M + 8.0 * N),   # anchors + GT read, int64 matched index written
         "match_heavy": 0.0,                              # tiles of match_assign done cooperatively: its bytes are counted there
-        "match_flag": 4.0 * B * M,
+        "match_init": 4.0 * B * M,                      # start value of every GT row maximum
         "match_restore": 0.0,                            # patches a few anchors; no mandatory traffic
         "sample": 0.0,                                   # reads a 1/64 sample of the large levels; no mandatory traffic
         "filter_redo": 0.0,                              # repeats a level only when its sampled bound was too high

@@ -312,7 +312,7 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_SELECT 8          /* od_select_candidates: top-k + decode + clip        */
 #define OD_KERNEL_NMS 9
 #define OD_KERNEL_MATCH_HEAVY 10     /* od_match_retinanet: cooperative kernel for GT-heavy tiles */
-#define OD_KERNEL_MATCH_FLAG 11     /* no longer launched (its work is part of the restore kernel); id kept */
+#define OD_KERNEL_MATCH_INIT 11     /* od_match_retinanet: start values of the row maxima and tile counters */
 #define OD_KERNEL_FOCAL_FWD 12      /* od_focal_loss_forward: the streaming kernel               */
 #define OD_KERNEL_FOCAL_BWD 13
 #define OD_KERNEL_BOX_LOSS_FWD 14   /* od_box_loss_forward: the streaming kernel                 */

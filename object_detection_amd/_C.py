@@ -71,7 +71,7 @@ SIGNATURES = {
 
 PROFILE_OFF, PROFILE_ALL = -1, -2
 KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
-                "select", "nms", "match_heavy", "match_flag", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo",
+                "select", "nms", "match_heavy", "match_init", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo",
                 "pack"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2

@@ -414,6 +414,14 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
     }
 }
 
+// Start values of one call: every GT row maximum = key(+0), the per-image heavy-tile counters = 0.  One small launch
+// instead of two memsets (a memset is a launch as well, and writes the whole strided maxima array).
+__global__ __launch_bounds__(256) void match_init_kernel(MatchWs ws, long long m_total, int batch, int want_restore) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (want_restore && i < m_total) ws.gt_max_key[i * GSTRIDE] = kZeroKey;
+    if (i < batch) ws.heavy_count[i * 16] = 0ull;
+}
+
 // Wave-cooperative re-examination of one tile against the GT range [g_begin, g_end) of its image: the IoUs
 // are recomputed with the same code as in the assign kernel (bit-identical values) and every anchor that
 // attains a GT's global maximum is restored.  All 64 lanes must call it with wave-uniform arguments.
@@ -826,8 +834,11 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     ws.list_stride = total_tiles;
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
     dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
-    if (restore) OD_HIP(hipMemsetD32Async((hipDeviceptr_t)ws.gt_max_key, (int)0x80000000u, (size_t)m_total * GSTRIDE, s));
-    OD_HIP(hipMemsetAsync(ws.heavy_count, 0, (size_t)batch * 128, s));
+    {
+        const long long init_threads = m_total > batch ? m_total : batch;
+        OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_INIT, match_init_kernel, dim3((unsigned)((init_threads + 255) / 256)), dim3(256),
+                         0, s, ws, (long long)m_total, (int)batch, restore);
+    }
     const long long stride = (long long)anchor_batch_stride;
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
                      (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,

@@ -16,6 +16,7 @@ from . import _C
 
 _workspaces: Dict[tuple, Tensor] = {}
 _small_cache: Dict[tuple, Tensor] = {}
+_ws_bytes: Dict[tuple, int] = {}     # answers of the *_workspace_bytes queries (pure functions of the sizes)
 
 
 def _require_gpu(t: Tensor, name: str) -> None:
@@ -136,7 +137,9 @@ def match_retinanet(anchors: Tensor, gt_list: Sequence[Tensor], high: float, low
     _require_gpu(gt, "target boxes")
     matched = torch.empty((B, n), dtype=torch.int64, device=dev)
     lib = _C.lib()
-    nbytes = lib.od_match_retinanet_workspace_bytes(m_total, B, n)
+    nbytes = _ws_bytes.get(("match", m_total, B, n))
+    if nbytes is None:
+        nbytes = _ws_bytes[("match", m_total, B, n)] = lib.od_match_retinanet_workspace_bytes(m_total, B, n)
     ws = _workspace(dev, "match", nbytes)
     rc = lib.od_match_retinanet(_ptr(anchors), stride, n, _ptr(gt), _ptr(offsets), m_total, B, float(high),
                                 float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws), ws.numel(),
@@ -387,7 +390,9 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
     out_labels = torch.empty((B, max_keep), dtype=torch.int64, device=dev) if want_labels else None
     out_count = torch.empty((B,), dtype=torch.int32, device=dev)
     lib = _C.lib()
-    nbytes = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
+    nbytes = _ws_bytes.get(("nms", B, num_seg, int(seg_stride)))
+    if nbytes is None:
+        nbytes = _ws_bytes[("nms", B, num_seg, int(seg_stride))] = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
     if nbytes == 0 and B > 0:
         raise _C.OdBoxesError(f"od_batched_nms: {num_seg * seg_stride} boxes per image exceed the limit "
                               f"of {_C.OD_MAX_NMS_BOXES}")
