@@ -177,6 +177,7 @@ def main():
     # per-image lists): one pinned row per step, filled by an asynchronous copy and read after the last step,
     # inside the timed region.  A step therefore never stalls the GPU on a host round trip.
     counts_host = torch.empty((max(args.steps, args.warmup, 3), cfg.batch), dtype=torch.int32).pin_memory()
+    count_rows = list(counts_host.unbind(0))              # the row views, made once
 
     # The two halves of a step are independent, so each gets a HIP stream of its own: the narrow kernels of the
     # inference half (top-k: 96 workgroups, NMS: one workgroup per image) then run beside the chip-wide matching
@@ -200,26 +201,32 @@ def main():
         if sync_host:
             oc.tolist()
         else:
-            counts_host[i].copy_(oc, non_blocking=True)
+            count_rows[i].copy_(oc, non_blocking=True)
         return oc
+
+    default_stream = torch.cuda.current_stream(dev)
 
     def step(i=0, sync_host=False, single_stream=False):
         if two and not sync_host and not single_stream:
+            # set_stream, not the `with torch.cuda.stream(...)` context manager: the manager's enter / exit cost the
+            # host several microseconds each, twice per step
             if os.environ.get("OD_BENCH_MATCH_FIRST"):
-                with torch.cuda.stream(s_matches[i % len(s_matches)]):
-                    matched = model.match_anchors(targets, anchors_per_image)
-                with torch.cuda.stream(s_posts[i % len(s_posts)]):
-                    oc = run_post(i, False)
-                return matched, oc
-            with torch.cuda.stream(s_posts[i % len(s_posts)]):
-                oc = run_post(i, False)
-            with torch.cuda.stream(s_matches[i % len(s_matches)]):
+                torch.cuda.set_stream(s_matches[i % len(s_matches)])
                 matched = model.match_anchors(targets, anchors_per_image)
+                torch.cuda.set_stream(s_posts[i % len(s_posts)])
+                oc = run_post(i, False)
+                return matched, oc
+            torch.cuda.set_stream(s_posts[i % len(s_posts)])
+            oc = run_post(i, False)
+            torch.cuda.set_stream(s_matches[i % len(s_matches)])
+            matched = model.match_anchors(targets, anchors_per_image)
             return matched, oc
+        torch.cuda.set_stream(default_stream)
         oc = run_post(i, sync_host)
         return model.match_anchors(targets, anchors_per_image), oc
 
     def sync():
+        torch.cuda.set_stream(default_stream)
         torch.cuda.synchronize(dev)
         if world > 1:
             import torch.distributed as dist
@@ -291,10 +298,10 @@ def main():
     dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"]
                    * probe[name]["cu_share"])
     dom_id = _C.KERNEL_NAMES.index(dominant)
-    # In the timed region every 8th launch of the dominant kernel is timed (start / stop events on the dispatch):
+    # In the timed region every 16th launch of the dominant kernel is timed (start / stop events on the dispatch):
     # a timed launch costs the host tens of microseconds, which would otherwise end up in `value`.
     _C.profile_select(dom_id)
-    _C.profile_stride(8)
+    _C.profile_stride(16)
     _C.profile_read(dom_id)
 
     sync()

@@ -61,3 +61,16 @@ for _ in range(200):
 pr.disable()
 torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+
+# Pure host cost of a step: a few steps issued into empty queues (the GPU cannot push back), best of 30 bursts
+import statistics
+for burst in (2, 4, 8):
+    samples = []
+    for _ in range(30):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(burst):
+            enqueue()
+        samples.append((time.perf_counter() - t0) / burst * 1e6)
+    torch.cuda.synchronize()
+    print("host only, bursts of %d steps: min %.1f us, median %.1f us per step" % (burst, min(samples), statistics.median(samples)))
