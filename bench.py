@@ -298,10 +298,10 @@ def main():
     dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"]
                    * probe[name]["cu_share"])
     dom_id = _C.KERNEL_NAMES.index(dominant)
-    # In the timed region every 16th launch of the dominant kernel is timed (start / stop events on the dispatch):
+    # In the timed region every 8th launch of the dominant kernel is timed (start / stop events on the dispatch):
     # a timed launch costs the host tens of microseconds, which would otherwise end up in `value`.
     _C.profile_select(dom_id)
-    _C.profile_stride(16)
+    _C.profile_stride(8)
     _C.profile_read(dom_id)
 
     sync()

@@ -30,7 +30,7 @@ def test_anchor_generate(device):
     assert torch.equal(out2.cpu(), ref2)
 
 
-@pytest.mark.parametrize("m", [1, 7, 100, 700])
+@pytest.mark.parametrize("m", [1, 7, 25, 100, 300, 513, 700])
 def test_match_retinanet(device, m):
     grids = (64, 32, 16, 8, 4)
     ag, anchors = _anchors_cpu((512, 512), grids, synthetic.retinanet_anchor_sizes(5, 32))
