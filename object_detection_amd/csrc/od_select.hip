@@ -72,6 +72,7 @@ struct FilterParams {
     // at memory position ch*plane + hw has flat index hw*chans + ch.  plane = 0: anchor-major [batch, N_l, C].
     unsigned int plane[OD_MAX_LEVELS];
     unsigned int chans[OD_MAX_LEVELS];
+    int defer[OD_MAX_LEVELS];               // 1: the level is filtered by filter_defer_kernel (DEFER_MIN logits or more)
 };
 
 struct SelectParams {
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
 #pragma unroll
     for (int i = 1; i < OD_MAX_LEVELS; ++i)
         if (i < p.num_levels && chunk >= p.chunk_start[i]) l = i;
+    if (p.defer[l]) return;                        // very large levels: filter_defer_kernel
     const long long slot = (long long)b * p.num_levels + l;
     const CutInfo ci = cuts[slot];
     float pre = p.pre_logit, cut = -__builtin_inff();
@@ -295,6 +297,210 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
         }
         for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
     }
+}
+
+// The same filter for very large levels (DEFER_MIN logits or more; one launch per such level).  There the sampled
+// cut leaves a key or two per 8192-logit chunk, and one slot reservation per chunk -- a returning atomic on the
+// level's single counter line, ~13 ns apart -- takes longer than reading the level (14 746 chunks of a 1536 x 1536,
+// 91-class finest level: ~190 us).  A workgroup here walks SUBS consecutive chunks, scores each chunk's candidates
+// at once but keeps the keys in the per-wave LDS queues, and reserves slots for all of them together: when a queue
+// could not take the next chunk's candidates, and at the end.  A chunk with more candidates than a queue holds
+// (dense input, no cut) is handled like in filter_kernel: per wave, four passes, a reservation each.
+constexpr long long DEFER_MIN = 8ll << 20;
+constexpr int SUBS = 8;
+
+__global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l, unsigned long long* __restrict__ keys,
+                                                          unsigned int* __restrict__ key_count,
+                                                          unsigned int* __restrict__ key_valid,
+                                                          unsigned int* __restrict__ key_count_redo,
+                                                          const CutInfo* __restrict__ cuts, int redo) {
+    constexpr int NWV = ST / 64;
+    constexpr int QCAP = 512;
+    static_assert(CHUNK / (ST * 4) == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
+    __shared__ unsigned long long s_queue[NWV][QCAP];
+    __shared__ int s_tot[2][NWV];
+    __shared__ unsigned int s_base;
+    __shared__ unsigned int s_valid;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const long long slot = (long long)b * p.num_levels + l;
+    const CutInfo ci = cuts[slot];
+    float pre = p.pre_logit, cut = -__builtin_inff();
+    int prefilter = p.prefilter;
+    if (redo) {
+        if (!(ci.active && key_valid[slot * CSTRIDE] < (unsigned int)p.topk)) return;
+    } else if (ci.active) {
+        pre = ci.pre;
+        cut = ci.cut;
+        prefilter = 1;
+    }
+    if (tid == 0) s_valid = 0u;
+    const long long E = p.level_elems[l];
+    const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
+    unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
+    unsigned int* counter = (redo ? key_count_redo : key_count) + slot * CSTRIDE;
+    unsigned long long* queue = s_queue[wave];
+    typedef float vec4f __attribute__((ext_vector_type(4)));
+
+    int held[NWV];                                 // keys waiting in every wave's queue (the same values in all waves)
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) held[w] = 0;
+    int nvalid_acc = 0;                            // valid keys of this wave since the last flush
+
+    // one reservation for everything the four queues hold, then the copy-out (all threads of the workgroup)
+    auto flush = [&]() {
+        int sum = 0, before_me = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { sum += held[w]; if (w < wave) before_me += held[w]; }
+        if (sum == 0) return;
+        if (lane == 0 && nvalid_acc) atomicAdd(&s_valid, (unsigned int)nvalid_acc);
+        nvalid_acc = 0;
+        __syncthreads();
+        if (tid == 0) {
+            s_base = atomicAdd(counter, (unsigned int)sum);
+            const unsigned int nv = s_valid;
+            s_valid = 0u;
+            if (!redo && nv) atomicAdd(key_valid + slot * CSTRIDE, nv);
+        }
+        __syncthreads();
+        const unsigned int base = s_base + (unsigned int)before_me;
+        int mine = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) if (w == wave) mine = held[w];
+        for (int i = lane; i < mine; i += 64) dst[base + i] = queue[i];
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) held[w] = 0;
+    };
+
+    const long long first_chunk = (long long)blockIdx.x * SUBS;
+    for (int sub = 0; sub < SUBS; ++sub) {
+        const long long e0 = (first_chunk + sub) * CHUNK;
+        if (e0 >= E) break;                                       // uniform
+        const bool vec_ok = (((uintptr_t)(src + e0)) & 15) == 0;
+        const long long rem = E - e0;
+        const int len = rem < CHUNK ? (int)rem : CHUNK;
+        vec4f v0, v1, v2, v3, v4, v5, v6, v7;
+        if (vec_ok && len == CHUNK) {
+            const vec4f* vp = reinterpret_cast<const vec4f*>(src + e0 + tid * 4);
+            v0 = __builtin_nontemporal_load(vp + 0 * ST); v1 = __builtin_nontemporal_load(vp + 1 * ST);
+            v2 = __builtin_nontemporal_load(vp + 2 * ST); v3 = __builtin_nontemporal_load(vp + 3 * ST);
+            v4 = __builtin_nontemporal_load(vp + 4 * ST); v5 = __builtin_nontemporal_load(vp + 5 * ST);
+            v6 = __builtin_nontemporal_load(vp + 6 * ST); v7 = __builtin_nontemporal_load(vp + 7 * ST);
+        } else {
+            auto ld4 = [&](int it) {
+                vec4f r;
+                const int off = it * ST * 4 + tid * 4;
+                r.x = (off + 0 < len) ? src[e0 + off + 0] : -__builtin_inff();
+                r.y = (off + 1 < len) ? src[e0 + off + 1] : -__builtin_inff();
+                r.z = (off + 2 < len) ? src[e0 + off + 2] : -__builtin_inff();
+                r.w = (off + 3 < len) ? src[e0 + off + 3] : -__builtin_inff();
+                return r;
+            };
+            v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
+        }
+        unsigned int pending_all = 0u;             // bit it*4+k: that element may reach the threshold
+        auto mark = [&](const vec4f& v, int it) {
+            unsigned int m = 0u;
+            m |= !(v.x <= pre) ? 1u : 0u; m |= !(v.y <= pre) ? 2u : 0u;
+            m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
+            pending_all |= m << (it * 4);
+        };
+        if (prefilter) {
+            mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
+        } else {
+            pending_all = 0xffffffffu;
+        }
+        if (len < CHUNK) {
+            unsigned int in_range = 0u;
+#pragma unroll
+            for (int i = 0; i < 32; ++i)
+                in_range |= ((i >> 2) * ST * 4 + tid * 4 + (i & 3) < len) ? (1u << i) : 0u;
+            pending_all &= in_range;
+        }
+        const int my_total = (int)wave_sum_all((uint32_t)__popc(pending_all));
+        if (lane == 0) s_tot[sub & 1][wave] = my_total;
+        __syncthreads();                           // (two buffers: the next chunk writes the other one)
+        int tot[NWV];
+        bool fits = true, dense = false;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            tot[w] = s_tot[sub & 1][w];
+            fits = fits && (held[w] + tot[w] <= QCAP);
+            dense = dense || (tot[w] > QCAP);
+        }
+        if (!fits) flush();                        // uniform: every wave sees the same numbers
+        // element e of this thread's 32 through a select tree; appends (logit, position in the chunk) entries
+        auto fill = [&](unsigned int pending, int pos) {
+            while (pending) {
+                const int e = __ffs(pending) - 1;
+                pending &= pending - 1u;
+                const bool b0 = e & 1, b1 = e & 2;
+                const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
+                const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
+                const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
+                const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
+                const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
+                const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
+                const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
+                const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
+                const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
+                const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
+                const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
+                const float xe = b4 ? h1 : h0;
+                const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+                queue[pos++] = ((unsigned long long)f2u(xe) << 32) | off;
+            }
+        };
+        // scores the queue entries [from, from + n) in place: key, or 0 for a logit that fails the exact test
+        auto score = [&](int from, int n) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int nvalid = 0;
+            for (int i0 = 0; i0 < n; i0 += 64) {
+                bool ok = false;
+                if (i0 + lane < n) {
+                    const unsigned long long ent = queue[from + i0 + lane];
+                    const uint32_t flat = flat_of(p, l, (uint32_t)e0 + (uint32_t)ent);
+                    const float sc = score_of(p, l, b, u2f((uint32_t)(ent >> 32)), flat);
+                    ok = sc > p.thresh && sc >= cut;
+                    queue[from + i0 + lane] = ok ? (((unsigned long long)f2u(sc) << 32) | (0xFFFFFFFFull - (unsigned long long)flat)) : 0ull;
+                }
+                nvalid += __popcll(__ballot(ok));
+            }
+            return nvalid;
+        };
+        if (!dense) {
+            int mine = 0, had = 0;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) if (w == wave) { mine = tot[w]; had = held[w]; }
+            const int my_cnt = __popc(pending_all);
+            const int incl = wave_inclusive_sum(my_cnt);
+            fill(pending_all, had + incl - my_cnt);
+            nvalid_acc += score(had, mine);
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) held[w] += tot[w];
+        } else {
+            // a chunk some wave cannot hold: nothing is deferred (the queues are empty here, see below); every wave
+            // makes four passes of 8 element slots (at most 64 * 8 = QCAP entries) with a reservation of its own
+            flush();                               // uniform; empties the queues if `fits` held above
+            for (int ps = 0; ps < 4; ++ps) {
+                const unsigned int pending = pending_all & (0xffu << (8 * ps));
+                const int my_cnt = __popc(pending);
+                const int incl = wave_inclusive_sum(my_cnt);
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                unsigned int base = 0;
+                if (total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
+                fill(pending, incl - my_cnt);
+                const int nvalid = score(0, total);
+                base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
+                if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
+                for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];
+            }
+        }
+    }
+    flush();
 }
 
 // ---- block-wide helpers for the select kernel ----------------------------------------------------
@@ -801,6 +1007,7 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
         sp.anchors[l] = on ? anchors[l] : nullptr;
         sp.anchor_stride[l] = on ? anchor_batch_stride[l] / 4 : 0;
         fp.plane[l] = fp.chans[l] = sp.plane[l] = sp.apl[l] = 0;
+        fp.defer[l] = (on && level_size[l] * (long long)num_classes >= DEFER_MIN) ? 1 : 0;
         if (on && plane_size && level_size[l] > 0) {
             const long long plane = plane_size[l];
             if (plane < 1 || level_size[l] % plane != 0) return OD_ERR_ARG;
@@ -858,9 +1065,21 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
         const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
         OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
                          key_count_redo, (const CutInfo*)cuts, 0);
+        for (int l = 0; l < num_levels; ++l) {
+            if (!fp.defer[l]) continue;
+            const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
+            OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_defer_kernel, dim3((unsigned)units, (unsigned)batch), dim3(ST), 0, s,
+                             fp, l, keys, key_count, key_valid, key_count_redo, (const CutInfo*)cuts, 0);
+        }
         if (sampled) {
             OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count,
                              key_valid, key_count_redo, (const CutInfo*)cuts, 1);
+            for (int l = 0; l < num_levels; ++l) {
+                if (!fp.defer[l]) continue;
+                const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
+                OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_defer_kernel, dim3((unsigned)units, (unsigned)batch),
+                                 dim3(ST), 0, s, fp, l, keys, key_count, key_valid, key_count_redo, (const CutInfo*)cuts, 1);
+            }
         }
     }
     OD_LAUNCH_KERNEL(OD_KERNEL_SELECT, select_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,

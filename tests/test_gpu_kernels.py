@@ -592,3 +592,28 @@ def test_pack_detections_is_the_gather_message(device, batch, max_det):
         kernels.pack_detections(dev[0], dev[1], dev[2].to(torch.int32), dev[3])
     with pytest.raises(ValueError):
         kernels.pack_detections(dev[0], dev[1][:, :-1] if max_det > 1 else dev[1][:0], dev[2], dev[3])
+
+
+def test_select_very_large_level_deferred_reservation(device):
+    """Levels of 8 Mi logits or more are filtered by workgroups that walk eight chunks and reserve key slots once:
+    (1) sampled bound active, a key or two per chunk; (2) threshold 0: every logit is a candidate (per-wave passes);
+    (3) the sample over-estimates the bound and the level is repeated without it; ragged level size, two images."""
+    gen = torch.Generator().manual_seed(88)
+    N, C = 2200003, 4                                         # E = 8 800 012: not a multiple of the chunk
+    E = N * C
+    dense = torch.empty((2, N, C)).normal_(-3.0, 1.5, generator=gen)
+    dense[1, :, 0] += 1.0
+    _check_select_single_level(device, dense, C, 0.05, 1000)
+    _check_select_single_level(device, dense[:1], C, 0.0, 500)
+    pos, S = _sampled_positions(E)
+    assert S == 131072 and pos.max() < E
+    flat = torch.full((E,), -6.0)
+    flat[torch.randperm(E, generator=gen)[:6000]] = 0.1 + 0.9 * torch.rand(6000, generator=gen)
+    # (samples within one logit unit: the bound sits 1e-4 below the located score, which must not admit 1000 samples)
+    flat[torch.from_numpy(pos)] = 2.0 + 1.0 * torch.rand(S, generator=gen)
+    flat[torch.randperm(E, generator=gen)[:300]] = 7.0
+    _check_select_single_level(device, flat.view(1, N, C), C, 0.5, 1000)
+    ws = kernels._workspaces[(torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream, "select")]
+    keys_bytes = (((E + 31) & ~31) * 8 + 255) & ~255
+    counters = ws[keys_bytes:keys_bytes + 3 * 256].view(torch.int32).cpu()
+    assert 0 < int(counters[64]) < 1000 and int(counters[128]) >= S, counters[[0, 64, 128]].tolist()
