@@ -553,8 +553,87 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {        // monotone m
 }
 __device__ __forceinline__ float from_ordered_bits(uint32_t k) { return u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
 
+// Sample of a level: S logits in runs of SAMPLE_RUN, one run per window of E / runs logits at a hashed offset; the
+// r-th best sample is the bound.  Returns false if the level gets no bound (small level, or the bound would remove
+// little).
+struct SampleGeometry { long long S; uint32_t window, spread; int r; };
+__device__ __forceinline__ bool sample_geometry(long long E, int topk, SampleGeometry* g) {
+    if (E < SAMPLE_MIN) return false;
+    long long S = (E / 64) & ~16383ll;
+    S = S < 16384 ? 16384 : (S > SAMPLE_MAX ? SAMPLE_MAX : S);
+    const long long runs = S / SAMPLE_RUN;
+    const long long window = E / runs;                         // >= 512 logits
+    const long long r64 = (3ll * topk * S + E - 1) / E + 32;
+    if (r64 > S / 4) return false;                             // the bound would remove little
+    g->S = S; g->window = (uint32_t)window; g->spread = (uint32_t)window - (SAMPLE_RUN - 1); g->r = (int)r64;
+    return true;
+}
+constexpr int SU = 16;                                         // samples per thread whose loads are in flight together
+constexpr long long SAMPLE_IN_REGS = 2 * SEL_T * SU;           // larger samples are gathered by several workgroups
+constexpr int SAMPLE_PART = SEL_T * SU;                        // samples per workgroup of sample_part_kernel
+constexpr int SAMPLE_PARTS_MAX = (int)(SAMPLE_MAX / SAMPLE_PART);
+
+// rank keys (0: cannot pass the threshold) of the samples base + u * SEL_T + tid, u < SU
+__device__ __forceinline__ void sample_keys(const FilterParams& p, int l, int b, const float* __restrict__ src,
+                                            const SampleGeometry& g, uint32_t base, uint32_t* key) {
+    const int tid = threadIdx.x;
+    float x[SU];
+    uint32_t pos[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        const uint32_t i = base + u * SEL_T + tid;
+        const uint32_t run = i / SAMPLE_RUN;
+        pos[u] = run * g.window + __umulhi(run * 2654435761u, g.spread) + (i % SAMPLE_RUN);
+        x[u] = src[pos[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        key[u] = 0u;
+        if (p.prefilter && x[u] <= p.pre_logit) continue;
+        if (p.has_ctr) {
+            const float sc = score_of(p, l, b, x[u], flat_of(p, l, pos[u]));
+            if (sc > p.thresh) key[u] = f2u(sc);
+        } else {
+            key[u] = ordered_bits(x[u]);
+        }
+    }
+}
+
+// Scratch of a large sample, in the level's own key region (free until the filter runs; S * 4 + parts * 16 KiB of
+// its E * 8 bytes): the S rank keys, then one 4096-bin histogram of their top 12 bits per part.
+__device__ __forceinline__ uint32_t* sample_stash(const FilterParams& p, unsigned long long* keys, int l, int b) {
+    return reinterpret_cast<uint32_t*>(keys + (long long)b * p.keys_per_image + p.key_off[l]);
+}
+
+// Gathering a large sample is bound by the latency of its scattered loads (one batch of 16 per thread takes ~5 us,
+// and one workgroup needs S / 16384 batches): the parts of such a sample are gathered by a workgroup each, which
+// leaves the rank keys and a partial histogram for sample_kernel.
+__global__ __launch_bounds__(SEL_T) void sample_part_kernel(FilterParams p, unsigned long long* __restrict__ keys) {
+    __shared__ unsigned int s_hist[HBINS];
+    const int tid = threadIdx.x;
+    const int part = blockIdx.x, l = blockIdx.y, b = blockIdx.z;
+    SampleGeometry g;
+    if (!sample_geometry(p.level_elems[l], p.topk, &g)) return;
+    if (g.S <= SAMPLE_IN_REGS || (long long)part * SAMPLE_PART >= g.S) return;
+    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
+    __syncthreads();
+    const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
+    uint32_t* stash = sample_stash(p, keys, l, b);
+    uint32_t key[SU];
+    sample_keys(p, l, b, src, g, (uint32_t)part * SAMPLE_PART, key);
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+        stash[(uint32_t)part * SAMPLE_PART + u * SEL_T + tid] = key[u];
+        if (key[u]) atomicAdd(&s_hist[key[u] >> 20], 1u);
+    }
+    __syncthreads();
+    uint32_t* hist = stash + g.S + (long long)part * HBINS;
+    for (int i = tid; i < HBINS; i += SEL_T) hist[i] = s_hist[i];
+}
+
 __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* __restrict__ cuts,
-                                                       unsigned int* __restrict__ counters, long long counter_words) {
+                                                       unsigned int* __restrict__ counters, long long counter_words,
+                                                       unsigned long long* __restrict__ keys) {
     __shared__ unsigned int s_hist[HBINS];
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
@@ -564,58 +643,19 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
     if (tid < 3) counters[tid * counter_words + ((long long)b * p.num_levels + l) * CSTRIDE] = 0u;
     CutInfo out;
     out.cut = 0.0f; out.pre = p.pre_logit; out.active = 0; out.pad = 0;
-    if (E < SAMPLE_MIN) {
+    SampleGeometry g;
+    if (!sample_geometry(E, p.topk, &g)) {
         if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
         return;
     }
-    long long S = (E / 64) & ~16383ll;
-    S = S < 16384 ? 16384 : (S > SAMPLE_MAX ? SAMPLE_MAX : S);
-    const long long runs = S / SAMPLE_RUN;
-    const long long window = E / runs;                         // >= 512 logits
-    const long long r64 = (3ll * p.topk * S + E - 1) / E + 32;
-    if (r64 > S / 4) {                                         // the cut would remove little
-        if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
-        return;
-    }
-    const int r = (int)r64;
+    const long long S = g.S;
+    const int r = g.r;
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
-    // f(rank key) for every sample that can pass the threshold; the loads of 16 samples are in flight together
-    // (S is a multiple of 16 * SEL_T)
-    const uint32_t window32 = (uint32_t)window, spread = window32 - (SAMPLE_RUN - 1);
-    constexpr int U = 16;
-    auto load_batch = [&](uint32_t base, uint32_t* key) {       // rank keys of 16 samples (0: cannot pass)
-        float x[U];
-        uint32_t pos[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t i = base + u * SEL_T + tid;
-            const uint32_t run = i / SAMPLE_RUN;
-            pos[u] = run * window32 + __umulhi(run * 2654435761u, spread) + (i % SAMPLE_RUN);
-            x[u] = src[pos[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            key[u] = 0u;
-            if (p.prefilter && x[u] <= p.pre_logit) continue;
-            if (p.has_ctr) {
-                const float sc = score_of(p, l, b, x[u], flat_of(p, l, pos[u]));
-                if (sc > p.thresh) key[u] = f2u(sc);
-            } else {
-                key[u] = ordered_bits(x[u]);
-            }
-        }
-    };
-    auto for_each_sample = [&](auto f) {
-        for (uint32_t base = 0; base < (uint32_t)S; base += SEL_T * U) {
-            uint32_t key[U];
-            load_batch(base, key);
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (key[u]) f(key[u]);
-        }
-    };
-    // up to 32 samples per thread stay in registers for the second pass; larger samples are read again
-    const bool in_regs = S <= 2 * SEL_T * U;
+    constexpr int U = SU;
+    auto load_batch = [&](uint32_t base, uint32_t* key) { sample_keys(p, l, b, src, g, base, key); };
+    const uint32_t* stash = sample_stash(p, keys, l, b);       // large samples: written by sample_part_kernel
+    // up to 32 samples per thread stay in registers for the second pass; larger samples come from the stash
+    const bool in_regs = S <= SAMPLE_IN_REGS;
     uint32_t kreg[2 * U];
     // pass A: the top 12 bits of the rank key
     for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
@@ -632,7 +672,12 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
         for (int u = 0; u < 2 * U; ++u)
             if (kreg[u]) atomicAdd(&s_hist[kreg[u] >> 20], 1u);
     } else {
-        for_each_sample([&](uint32_t k) { atomicAdd(&s_hist[k >> 20], 1u); });
+        const int parts = (int)(S / SAMPLE_PART);
+        for (int i = tid; i < HBINS; i += SEL_T) {
+            unsigned int c = 0;
+            for (int q = 0; q < parts; ++q) c += stash[S + (long long)q * HBINS + i];
+            s_hist[i] = c;
+        }
     }
     __syncthreads();
     find_cut_bin(s_hist, HBINS, r, s_tmp);
@@ -650,9 +695,14 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
         for (int u = 0; u < 2 * U; ++u)
             if (kreg[u] && (int)(kreg[u] >> 20) == bin1) atomicAdd(&s_hist[(kreg[u] >> 8) & 0xFFFu], 1u);
     } else {
-        for_each_sample([&](uint32_t k) {
-            if ((int)(k >> 20) == bin1) atomicAdd(&s_hist[(k >> 8) & 0xFFFu], 1u);
-        });
+        for (uint32_t base = 0; base < (uint32_t)S; base += SEL_T * U) {      // S is a multiple of SEL_T * U
+            uint32_t k[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) k[u] = stash[base + u * SEL_T + tid];  // all loads of a batch in flight together
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k[u] && (int)(k[u] >> 20) == bin1) atomicAdd(&s_hist[(k[u] >> 8) & 0xFFFu], 1u);
+        }
     }
     __syncthreads();
     find_cut_bin(s_hist, HBINS, r - above, s_tmp);
@@ -1059,8 +1109,14 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
 
     bool sampled = false;                          // does any level get a sampled cut?
     for (int l = 0; l < num_levels; ++l) sampled = sampled || fp.level_elems[l] >= SAMPLE_MIN;
+    bool large_sample = false;                     // does any level's sample exceed what one workgroup keeps in registers?
+    for (int l = 0; l < num_levels; ++l) large_sample = large_sample || ((fp.level_elems[l] / 64) & ~16383ll) > SAMPLE_IN_REGS;   // S of sample_geometry
+    if (large_sample) {
+        OD_LAUNCH_KERNEL(OD_KERNEL_SAMPLE, sample_part_kernel,
+                         dim3((unsigned)SAMPLE_PARTS_MAX, (unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s, fp, keys);
+    }
     OD_LAUNCH_KERNEL(OD_KERNEL_SAMPLE, sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,
-                     fp, cuts, key_count, (long long)(lay.counter_bytes / 4));
+                     fp, cuts, key_count, (long long)(lay.counter_bytes / 4), keys);
     if (lay.total_chunks > 0) {
         const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
         OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
