@@ -137,7 +137,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
                                                     unsigned int* __restrict__ key_count,
                                                     unsigned int* __restrict__ key_valid,
                                                     unsigned int* __restrict__ key_count_redo,
-                                                    const CutInfo* __restrict__ cuts, int redo) {
+                                                    const CutInfo* __restrict__ cuts, int redo, int chunk_base) {
     constexpr int ITERS = CHUNK / (ST * 4);
     constexpr int QCAP = 512;                      // queue entries per wave and pass
     static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     __shared__ unsigned int s_valid;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x;
+    const int chunk = (int)blockIdx.x + chunk_base;   // chunk_base: the chunks of leading deferred levels are not launched
     const int b = blockIdx.y;
     int l = 0;
 #pragma unroll
@@ -1118,9 +1118,13 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
     OD_LAUNCH_KERNEL(OD_KERNEL_SAMPLE, sample_kernel, dim3((unsigned)num_levels, (unsigned)batch), dim3(SEL_T), 0, s,
                      fp, cuts, key_count, (long long)(lay.counter_bytes / 4), keys);
     if (lay.total_chunks > 0) {
-        const dim3 grid((unsigned)lay.total_chunks, (unsigned)batch);
-        OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
-                         key_count_redo, (const CutInfo*)cuts, 0);
+        int lead = 0;                              // deferred levels at the head of the list (the finest ones, usually)
+        while (lead < num_levels && fp.defer[lead]) ++lead;
+        const int chunk_base = lay.chunk_start[lead];
+        const dim3 grid((unsigned)(lay.total_chunks - chunk_base), (unsigned)batch);
+        if (grid.x > 0)
+            OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
+                             key_count_redo, (const CutInfo*)cuts, 0, chunk_base);
         for (int l = 0; l < num_levels; ++l) {
             if (!fp.defer[l]) continue;
             const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
@@ -1128,8 +1132,9 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
                              fp, l, keys, key_count, key_valid, key_count_redo, (const CutInfo*)cuts, 0);
         }
         if (sampled) {
-            OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count,
-                             key_valid, key_count_redo, (const CutInfo*)cuts, 1);
+            if (grid.x > 0)
+                OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count,
+                                 key_valid, key_count_redo, (const CutInfo*)cuts, 1, chunk_base);
             for (int l = 0; l < num_levels; ++l) {
                 if (!fp.defer[l]) continue;
                 const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
