@@ -360,13 +360,25 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
                     dead = dead || sup;
                 }
             }
-            for (int e = KC + part; e < nk; e += parts) {      // kept boxes beyond the LDS cache
-                const int kp = s_kept[e];
-                const float4 kb = make_float4(sx1[kp], sy1[kp], sx2[kp], sy2[kp]);
-                const float inter = intersection(kb, jb);
-                bool sup = over_threshold_exact(inter, sar[kp], jar, thr.up);
-                if (vanilla) sup = sup && (slab[kp] == jlab);
-                dead = dead || sup;
+            // kept boxes beyond the LDS cache come from the workspace, four at a time so that their loads overlap
+            for (int e0 = KC + part * 4; e0 < nk; e0 += parts * 4) {
+                float4 kb[4];
+                float kar[4];
+                int klab[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kp = s_kept[(e0 + u < nk) ? e0 + u : nk - 1];     // tail repeats the last kept box
+                    kb[u] = make_float4(sx1[kp], sy1[kp], sx2[kp], sy2[kp]);
+                    kar[u] = sar[kp];
+                    klab[u] = slab[kp];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float inter = intersection(kb[u], jb);
+                    bool sup = over_threshold_exact(inter, kar[u], jar, thr.up);
+                    if (vanilla) sup = sup && (klab[u] == jlab);
+                    dead = dead || sup;
+                }
             }
             if (dead && valid) s_dead[c] = 1;
         }
