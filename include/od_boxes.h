@@ -178,6 +178,23 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
                    size_t workspace_bytes, void* stream);
 
 /*
+ * od_batched_nms for callers that cannot allocate device memory or carry a workspace: code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.  Same arguments, results
+ * and error codes as od_batched_nms, without the workspace: the kernels' scratch memory is a device array of
+ * OD_NMS_NOALLOC_SCRATCH_BYTES inside the library (one copy per GPU, held until the process ends).  The call allocates
+ * and frees nothing; the device that `stream` belongs to must be the current device.
+ *   limit: od_batched_nms_workspace_bytes(batch, num_seg, seg_stride) <= OD_NMS_NOALLOC_SCRATCH_BYTES (e.g. 16 images
+ *   of 8192 boxes), otherwise OD_ERR_LIMIT (-2).
+ *   All calls on one GPU share the array: calls that can overlap in time on one GPU (two streams, two threads) race
+ *   and must be serialised by the caller.
+ */
+#define OD_NMS_NOALLOC_SCRATCH_BYTES (8u << 20)
+int od_batched_nms_noalloc(const float* boxes, const float* scores, const int32_t* labels, const int32_t* seg_count,
+                           int32_t num_seg, int32_t seg_stride, int32_t segments_sorted, int32_t batch,
+                           double iou_threshold, int32_t mode, int32_t max_keep, int64_t* keep_idx, float* out_boxes,
+                           float* out_scores, int64_t* out_labels, int32_t* out_count, void* stream);
+
+/*
  * Message of the detections all-gather: the padded outputs of od_batched_nms for the local images, packed into
  * one fp32 row per image so that one collective moves them.  No counterpart in the reference, which runs one
  * process on one device (train.py:24, predict.py:25); this is the only exchange of the image-sharded pipeline.

@@ -18,6 +18,7 @@ OD_MAX_LEVELS = 8
 OD_MAX_BASE_ANCHORS = 16
 OD_MAX_TOPK = 4096
 OD_MAX_NMS_BOXES = 8192
+OD_NMS_NOALLOC_SCRATCH_BYTES = 8 << 20
 CODER_BOXCODER, CODER_LINEAR = 0, 1
 NMS_TRICK, NMS_VANILLA, NMS_AUTO_CPU, NMS_AUTO_GPU = 0, 1, 2, 3
 
@@ -48,6 +49,8 @@ SIGNATURES = {
     "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "od_batched_nms_noalloc": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
+                                         _P, _P, _P, _P, _P, _P]),
     "od_pack_detections": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P]),
     "od_focal_loss_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "od_focal_loss_forward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,

@@ -24,6 +24,8 @@
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
+#include <mutex>
+
 namespace {
 
 using namespace od;
@@ -572,7 +574,7 @@ extern "C" size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg,
     return (b + 255) & ~(size_t)255;
 }
 
-extern "C" int od_batched_nms(const float* boxes, const float* scores, const int32_t* labels,
+static int batched_nms_launch(const float* boxes, const float* scores, const int32_t* labels,
                               const int32_t* seg_count, int32_t num_seg, int32_t seg_stride,
                               int32_t segments_sorted, int32_t batch, double iou_threshold, int32_t mode,
                               int32_t max_keep, int64_t* keep_idx, float* out_boxes, float* out_scores,
@@ -615,6 +617,65 @@ extern "C" int od_batched_nms(const float* boxes, const float* scores, const int
     }
     OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
     return OD_OK;
+}
+
+extern "C" int od_batched_nms(const float* boxes, const float* scores, const int32_t* labels,
+                              const int32_t* seg_count, int32_t num_seg, int32_t seg_stride,
+                              int32_t segments_sorted, int32_t batch, double iou_threshold, int32_t mode,
+                              int32_t max_keep, int64_t* keep_idx, float* out_boxes, float* out_scores,
+                              int64_t* out_labels, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+    return batched_nms_launch(boxes, scores, labels, seg_count, num_seg, seg_stride, segments_sorted, batch,
+                              iou_threshold, mode, max_keep, keep_idx, out_boxes, out_scores, out_labels, out_count,
+                              workspace, workspace_bytes, stream);
+}
+
+// ---- od_batched_nms for callers that cannot allocate ---------------------------------------------------------
+// The scratch memory of the NMS kernels (the sorted boxes of every image in SoA form) lives in a device array that
+// is part of the library's code object, so the entry point needs no workspace argument and allocates nothing.
+// Every GPU holds its own copy of the array at its own address: the address is looked up once per device
+// (hipGetSymbolAddress with that device current) and host code only ever uses that pointer -- the array's name is
+// not a device address on the host side.  All calls on one GPU share the array: calls that overlap in time on one
+// GPU (different streams, different threads) race.  Nothing in it has to start at zero: the kernels write every
+// element they later read.
+constexpr size_t SCRATCH_BYTES = OD_NMS_NOALLOC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+static std::mutex g_scratch_mu;
+static void* g_scratch_ptr[MAX_DEVICES];
+
+// Device address of `scratch` on the current device (looked up on the first call per device).
+static int scratch_pointer(void** out) {
+    int dev = -1;
+    OD_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return OD_ERR_LIMIT;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        OD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (p == nullptr) return OD_ERR_ARG;
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return OD_OK;
+}
+
+extern "C" int od_batched_nms_noalloc(const float* boxes, const float* scores, const int32_t* labels,
+                                      const int32_t* seg_count, int32_t num_seg, int32_t seg_stride,
+                                      int32_t segments_sorted, int32_t batch, double iou_threshold, int32_t mode,
+                                      int32_t max_keep, int64_t* keep_idx, float* out_boxes, float* out_scores,
+                                      int64_t* out_labels, int32_t* out_count, void* stream) {
+    if (batch < 0 || num_seg < 1 || seg_stride < 1 || max_keep < 0) return OD_ERR_ARG;
+    if (batch == 0) return OD_OK;
+    const size_t need = od_batched_nms_workspace_bytes(batch, num_seg, seg_stride);
+    if (need == 0 || need > SCRATCH_BYTES) return OD_ERR_LIMIT;      // beyond the built-in scratch array
+    void* ws = nullptr;
+    const int rc = scratch_pointer(&ws);
+    if (rc != OD_OK) return rc;
+    return batched_nms_launch(boxes, scores, labels, seg_count, num_seg, seg_stride, segments_sorted, batch,
+                              iou_threshold, mode, max_keep, keep_idx, out_boxes, out_scores, out_labels, out_count,
+                              ws, SCRATCH_BYTES, stream);
 }
 
 extern "C" int od_pack_detections(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,

@@ -63,6 +63,11 @@ def test_argument_errors_without_gpu():
     assert lib.od_batched_nms(ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16), 1, 9000, 0, 1, 0.5, 0,
                               10, null, ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16),
                               ctypes.c_void_p(256), 1 << 30, null) == -2
+    # the no-allocation variant rejects sizes beyond its built-in scratch array before anything touches a GPU
+    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 1024, 1, 64, 0.5, 0, 10, null, null, null, null, null,
+                                      null) == -2
+    assert lib.od_batched_nms_noalloc(null, null, null, null, 0, 10, 0, 1, 0.5, 0, 10, null, null, null, null, null,
+                                      null) == -1
     assert lib.od_profile_select(99) == -1
     with pytest.raises(_C.OdBoxesError):
         _C.check(-3, "x")

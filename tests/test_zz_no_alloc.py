@@ -1,0 +1,70 @@
+"""od_batched_nms_noalloc (scratch memory inside the library, no workspace argument, no allocation) returns, bit for
+bit, what od_batched_nms returns: called through the C ABI twice in a row, the second time on a smaller input, so
+that leftovers of the first call in the shared scratch array would show."""
+import ctypes
+
+import pytest
+import torch
+
+from object_detection_amd import _C, kernels
+
+pytestmark = pytest.mark.gpu
+
+
+def _inputs(batch, num_seg, seg_stride, classes, seed, device):
+    gen = torch.Generator().manual_seed(seed)
+    n = num_seg * seg_stride
+    xy = torch.rand((batch, n, 2), generator=gen) * 600.0
+    wh = torch.rand((batch, n, 2), generator=gen) * 90.0 + 1.0
+    boxes = torch.cat([xy, xy + wh], dim=2)
+    scores = torch.rand((batch, n), generator=gen)
+    scores[:, ::5] = scores[:, :1]                                   # ties in score
+    # pre-sorted segments, as the candidate selection hands them over: (score desc, index asc) inside each segment
+    scores = scores.view(batch, num_seg, seg_stride).sort(dim=2, descending=True, stable=True)[0].reshape(batch, n)
+    labels = torch.randint(0, classes, (batch, n), generator=gen, dtype=torch.int32)
+    counts = torch.randint(seg_stride // 2, seg_stride + 1, (batch, num_seg), generator=gen, dtype=torch.int32)
+    counts[0, 0] = 0                                                  # an empty segment
+    return [t.to(device).contiguous() for t in (boxes, scores, labels, counts)]
+
+
+def _outputs(batch, max_keep, device):
+    return (torch.full((batch, max_keep), -7, dtype=torch.int64, device=device),
+            torch.full((batch, max_keep, 4), -7.0, device=device),
+            torch.full((batch, max_keep), -7.0, device=device),
+            torch.full((batch, max_keep), -7, dtype=torch.int64, device=device),
+            torch.full((batch,), -7, dtype=torch.int32, device=device))
+
+
+def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, seed):
+    lib = _C.lib()
+    boxes, scores, labels, counts = _inputs(batch, num_seg, seg_stride, classes, seed, device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    want = _outputs(batch, max_keep, device)
+    nbytes = lib.od_batched_nms_workspace_bytes(batch, num_seg, seg_stride)
+    assert 0 < nbytes <= _C.OD_NMS_NOALLOC_SCRATCH_BYTES
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    rc = lib.od_batched_nms(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, 1, batch, thr, mode, max_keep,
+                            *[p(t) for t in want], p(ws), nbytes, stream)
+    assert rc == 0
+    got = _outputs(batch, max_keep, device)
+    rc = lib.od_batched_nms_noalloc(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, 1, batch, thr, mode,
+                                    max_keep, *[p(t) for t in got], stream)
+    assert rc == 0
+    torch.cuda.synchronize(device)
+    assert int(want[4].min()) >= 0 and int(want[4].max()) > 0
+    for name, a, b in zip(("keep_idx", "boxes", "scores", "labels", "count"), got, want):
+        assert torch.equal(a, b), f"{name} differs (batch {batch}, {num_seg} x {seg_stride})"
+    return want[4].cpu().tolist()
+
+
+def test_noalloc_nms_matches_workspace_nms_twice(device):
+    # the larger input first: 16 images x 6 segments x 1000 candidates, then 3 images x 4 x 300 in the same scratch
+    first = _run_both(device, 16, 6, 1000, 4, 500, 0.3, _C.NMS_AUTO_GPU, seed=1)
+    second = _run_both(device, 3, 4, 300, 91, 100, 0.5, _C.NMS_VANILLA, seed=2)
+    assert max(first) == 500 and len(second) == 3
+    # beyond the built-in scratch array: rejected, nothing launched
+    lib = _C.lib()
+    null = ctypes.c_void_p(0)
+    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 1024, 1, 64, 0.5, 0, 10, null, null, null, null, null,
+                                      null) == -2
