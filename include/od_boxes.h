@@ -30,8 +30,8 @@ extern "C" {
 
 #define OD_MAX_LEVELS 8
 #define OD_MAX_BASE_ANCHORS 16
-#define OD_MAX_TOPK 4096        /* topk_candidates limit of od_select_candidates */
-#define OD_MAX_NMS_BOXES 8192   /* boxes per image limit of od_batched_nms */
+#define OD_MAX_TOPK 8192        /* topk_candidates limit of od_select_candidates */
+#define OD_MAX_NMS_BOXES 65536  /* boxes per image limit of od_batched_nms */
 
 #define OD_CODER_BOXCODER 0     /* BoxCoder(weights=(1,1,1,1)).decode_single  (RetinaNet) */
 #define OD_CODER_LINEAR 1       /* BoxLinearCoder(normalize_by_size=True).decode (FCOS)   */
@@ -40,6 +40,11 @@ extern "C" {
 #define OD_NMS_VANILLA 1        /* _batched_nms_vanilla          */
 #define OD_NMS_AUTO_CPU 2       /* batched_nms rule for device.type == "cpu": numel > 4000 -> vanilla */
 #define OD_NMS_AUTO_GPU 3       /* batched_nms rule otherwise:               numel > 20000 -> vanilla */
+/* Threshold rule, or-ed into the mode.  torchvision's two native kernels disagree for an IoU that equals
+ * float(iou_threshold): csrc/ops/cpu/nms_kernel.cpp promotes the fp32 IoU to double and compares with the double
+ * threshold (the default here); csrc/ops/cuda/nms_kernel.cu compares the fp32 IoU with the threshold rounded to
+ * float (this flag).  The reference runs on "cuda" when available (train.py:24, predict.py:25). */
+#define OD_NMS_THRESHOLD_FLOAT 0x100
 
 /* Library version (major*10000 + minor*100 + patch). */
 int od_version(void);
@@ -161,14 +166,16 @@ int od_select_candidates_planar(const float* const* cls_logits, const int64_t* c
  * (_batched_nms_coordinate_trick / _batched_nms_vanilla) + the native torchvision::nms op +
  * `keep[:max_keep]` + the gather of boxes/scores/labels (tail of postprocess_detections).
  * Greedy order = stable descending score (ties: lower index first); box j is suppressed by a kept
- * box i when fp32 inter/(area_i+area_j-inter), promoted to double, is > iou_threshold.
+ * box i when fp32 inter/(area_i+area_j-inter), promoted to double, is > iou_threshold (with OD_NMS_THRESHOLD_FLOAT
+ * in `mode`: when the fp32 quotient is > (float)iou_threshold).
  *   boxes [batch, num_seg*seg_stride, 4], scores, labels (int32, NULL = one class): padded segments;
  *   seg_count int32 [batch, num_seg]: valid entries at the head of each segment (device).
  *   segments_sorted: nonzero if every segment is already in (score desc, index asc) order.
  *   Indices written to keep_idx count valid entries only (the index a torch.cat of the segments
  *   would give).  Outputs: keep_idx int64 [batch, max_keep] (may be NULL), out_boxes fp32
  *   [batch, max_keep, 4], out_scores fp32, out_labels int64 (NULL allowed), out_count int32 [batch].
- *   Rows past out_count are zero-filled.  Limit: num_seg*seg_stride <= OD_MAX_NMS_BOXES.
+ *   Rows past out_count are zero-filled.  Limits: num_seg*seg_stride <= OD_MAX_NMS_BOXES, num_seg <= 64.
+ *   Up to 8 sorted segments are merged lazily, strip by strip; unsorted input is ranked first (O(n^2) comparisons).
  */
 size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride);
 int od_batched_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* seg_count,
@@ -338,7 +345,8 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_SAMPLE 17         /* od_select_candidates: sampled score bound per (image, level)   */
 #define OD_KERNEL_FILTER_REDO 18    /* od_select_candidates: second filter pass (normally exits at once) */
 #define OD_KERNEL_PACK 19           /* od_pack_detections */
-#define OD_KERNEL_COUNT 20
+#define OD_KERNEL_NMS_ORDER 20      /* od_batched_nms: global order of unsorted candidates */
+#define OD_KERNEL_COUNT 21
 int od_profile_select(int32_t kernel_id);
 /* Time only every `every`-th launch of a selected kernel (default 1): a timed launch costs the host tens of
  * microseconds, which a throughput measurement should not pay on every step. */

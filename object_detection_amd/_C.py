@@ -16,11 +16,12 @@ LIB_PATH = os.path.join(_HERE, "libod_boxes.so")
 
 OD_MAX_LEVELS = 8
 OD_MAX_BASE_ANCHORS = 16
-OD_MAX_TOPK = 4096
-OD_MAX_NMS_BOXES = 8192
+OD_MAX_TOPK = 8192
+OD_MAX_NMS_BOXES = 65536
 OD_NMS_NOALLOC_SCRATCH_BYTES = 8 << 20
 CODER_BOXCODER, CODER_LINEAR = 0, 1
 NMS_TRICK, NMS_VANILLA, NMS_AUTO_CPU, NMS_AUTO_GPU = 0, 1, 2, 3
+NMS_THRESHOLD_FLOAT = 0x100     # or-ed into the mode: compare the fp32 IoU with float(threshold), as torchvision's CUDA kernel
 
 _ERRORS = {
     -1: "invalid argument (null pointer, negative size, misaligned or inconsistent shapes)",
@@ -75,7 +76,7 @@ SIGNATURES = {
 PROFILE_OFF, PROFILE_ALL = -1, -2
 KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
                 "select", "nms", "match_heavy", "match_init", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo",
-                "pack"]
+                "pack", "nms_order"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 LOSS_NORM_PER_IMAGE, LOSS_NORM_BATCH = 0, 1

@@ -36,30 +36,37 @@ def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:
     return out
 
 
-def _nms_device_mode(boxes: Tensor) -> int:
-    # torchvision.ops.boxes.batched_nms: numel > 4000 on cpu, > 20000 elsewhere -> per-class NMS
-    return _C.NMS_AUTO_CPU if boxes.device.type == "cpu" else _C.NMS_AUTO_GPU
+# What torchvision does for tensors on a GPU, which is where these operators run: batched_nms takes the per-class
+# branch when numel > 20000 (4000 on the CPU), and the native CUDA kernel compares the fp32 IoU with the threshold
+# rounded to float (the CPU kernel promotes the IoU to double).  ``threshold_rule="cpu"`` selects the CPU kernel's
+# comparison instead; the two differ only for an IoU that equals float(iou_threshold).
+def _threshold_flag(threshold_rule: str) -> int:
+    if threshold_rule not in ("cuda", "cpu"):
+        raise ValueError(f"threshold_rule must be 'cuda' or 'cpu', got {threshold_rule!r}")
+    return _C.NMS_THRESHOLD_FLOAT if threshold_rule == "cuda" else 0
 
 
-def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, threshold_rule: str = "cuda") -> Tensor:
     """Indices kept by greedy NMS, sorted by decreasing score (stable), int64."""
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     cnt = kernels._device_ints([n], boxes.device).reshape(1, 1)
     keep, _, _, _, count = kernels.batched_nms_padded(boxes.reshape(1, n, 4), scores.reshape(1, n), None, cnt, n,
-                                                      False, float(iou_threshold), _C.NMS_TRICK, n,
+                                                      False, float(iou_threshold),
+                                                      _C.NMS_TRICK | _threshold_flag(threshold_rule), n,
                                                       want_labels=False)
     return keep[0, : int(count.item())]
 
 
-def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float, mode: int = None) -> Tensor:
+def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: float, mode: int = None,
+                threshold_rule: str = "cuda") -> Tensor:
     """Per-class NMS.  ``mode`` overrides torchvision's size rule (``_C.NMS_TRICK`` / ``_C.NMS_VANILLA``)."""
     n = boxes.shape[0]
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     cnt = kernels._device_ints([n], boxes.device).reshape(1, 1)
-    mode = _nms_device_mode(boxes) if mode is None else mode
+    mode = (_C.NMS_AUTO_GPU if mode is None else (mode & 0xff)) | _threshold_flag(threshold_rule)
     keep, _, _, _, count = kernels.batched_nms_padded(boxes.reshape(1, n, 4), scores.reshape(1, n),
                                                       idxs.reshape(1, n), cnt, n, False, float(iou_threshold), mode,
                                                       n, want_labels=False)

@@ -1,26 +1,29 @@
 // Class-batched non-maximum suppression, one 1024-thread workgroup per image.
 // Replaces torchvision.ops.boxes.batched_nms (_batched_nms_coordinate_trick / _batched_nms_vanilla),
-// the native torchvision::nms op (csrc/ops/cpu/nms_kernel.cpp semantics), `keep[:detections_per_img]`
-// and the gather of the kept boxes/scores/labels at the tail of postprocess_detections
-// (reference trigger object_detection/train.py:84, object_detection/predict.py:61, and the plain
-// nms call at object_detection/predict.py:72).
+// the native torchvision::nms op (csrc/ops/cpu/nms_kernel.cpp or csrc/ops/cuda/nms_kernel.cu semantics),
+// `keep[:detections_per_img]` and the gather of the kept boxes/scores/labels at the tail of
+// postprocess_detections (reference trigger object_detection/train.py:84, object_detection/predict.py:61, and the
+// plain nms call at object_detection/predict.py:72).
 //
-// Algorithm (greedy NMS is inherently ordered; the work around the order is made parallel):
-//   1. order: unique keys (ordered score bits << 32 | ~slot) give the stable descending order.
-//      Pre-sorted segments (the per-level candidate lists of the pipeline) are merged with a
-//      merge-path tree in LDS (O(n) work per round); arbitrary input is bitonic-sorted in LDS.
-//   2. the sorted boxes are gathered once into an SoA workspace (coordinate-trick offsets applied).
-//   3. candidates are consumed in strips of 256 in sorted order, stopping as soon as max_keep boxes
-//      are kept:
-//        A. every strip candidate is tested against the boxes kept so far (kept boxes live in LDS
-//           and are read as broadcasts; 4 thread groups split the kept list);
-//        B. the still-alive candidates are compacted into LDS and their pairwise suppression bits
-//           (row i suppresses column j, i < j) are computed by all 16 waves into an LDS bit matrix
-//           stored per column;
-//        C. one wave resolves the strip 64 candidates at a time: a column is dead if its bit column
-//           meets the kept set of earlier blocks; inside a block the greedy result is the fixed
-//           point of  kept = alive & ~(exists kept i<j suppressing j), reached by ballot iteration.
-//   4. kept boxes are gathered to the outputs in order; rows past the count are zero-filled.
+// Greedy NMS is ordered by score; the kernel consumes the candidates in that order in strips of up to 256 and
+// stops as soon as max_keep boxes are kept, so only the head of the order is ever produced:
+//   1. order, lazily.  The pipeline hands over one pre-sorted segment per pyramid level.  The next strip of the
+//      global order lies inside the next 256 entries of every segment: those windows are loaded into LDS, every
+//      window entry finds its rank among all windows by binary search in the other windows, and the entries of
+//      rank < strip length form the strip.  No global sort or merge of all candidates is ever made.  Unsorted
+//      input (or more than 8 segments) is ranked beforehand by nms_order_kernel and read as one sorted segment.
+//   2. classes never interact (vanilla mode by definition; coordinate-trick mode because the offsets
+//      label * (max + 1) move the classes to disjoint coordinate ranges -- verified per image, see `independent`).
+//      A strip is therefore re-ordered by (class, rank); waves then hold candidates of one class, and
+//        A. every candidate is tested against the boxes kept so far, which sit in LDS grouped by strip and class:
+//           a group of four kept boxes without the wave's class is skipped after one label comparison;
+//        B. the candidates still alive are compacted and each tests only the earlier alive candidates of its own
+//           class (suppression bits into an LDS bit matrix, one column per candidate);
+//        C. one wave resolves the strip 64 columns at a time: a column is dead if its bit column meets the kept
+//           set of earlier blocks; inside a block the greedy result is the fixed point of
+//           kept = alive & ~(exists kept i<j suppressing j), reached by ballot iteration;
+//      the newly kept boxes are appended to the kept list in class order and to the output list in score order.
+//   3. kept boxes are gathered to the outputs in order; rows past the count are zero-filled.
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
@@ -34,39 +37,26 @@ constexpr int NT = 1024;              // threads per workgroup
 constexpr int S = 256;                // strip length
 constexpr int SB = S / 64;            // 64-candidate blocks per strip
 constexpr int MAXN = OD_MAX_NMS_BOXES;
-constexpr int MERGE_MAX = 6144;       // merge-path ordering needs a second key buffer of this many keys
-constexpr int KC = 1024;              // kept boxes cached in LDS (later ones are read from the workspace)
+constexpr int WSEG = 8;               // pre-sorted segments that are merged lazily (more: ranked beforehand)
+constexpr int KC = 1024;              // kept boxes cached in LDS (later ones are read through the workspace)
 constexpr int CW = SB * 2 + 1;        // u32 words per column of the bit matrix (+1 pad against bank conflicts)
 constexpr int MAX_SEG = 64;
-
-// LDS carve-up (bytes).  Region B holds the second key buffer while ordering, afterwards the strip state.
-constexpr int OFF_A = 0;                               // u64 keys[MAXN]
-constexpr int OFF_B = OFF_A + MAXN * 8;                // u64 keys2[MERGE_MAX]  |  strip state:
-constexpr int OFF_KBOX = OFF_B;                        //   float4 k_box[KC]
-constexpr int OFF_KAR = OFF_KBOX + KC * 16;            //   float   k_ar[KC]
-constexpr int OFF_KLAB = OFF_KAR + KC * 4;             //   int     k_lab[KC]
-constexpr int OFF_KEPT = OFF_KLAB + KC * 4;            //   u16     kept[MAXN]   (sorted positions)
-constexpr int OFF_ABOX = OFF_KEPT + MAXN * 2;          //   float4  a_box[S]     (alive strip candidates)
-constexpr int OFF_AAR = OFF_ABOX + S * 16;             //   float   a_ar[S]
-constexpr int OFF_ALAB = OFF_AAR + S * 4;              //   int     a_lab[S]
-constexpr int OFF_APOS = OFF_ALAB + S * 4;             //   int     a_pos[S]     (sorted position)
-constexpr int END_B = OFF_APOS + S * 4;
-static_assert(END_B <= OFF_B + MERGE_MAX * 8, "strip state must fit in the second key buffer");
-constexpr int OFF_ORDER = OFF_B + MERGE_MAX * 8;       // u16 order[MAXN]
-constexpr int OFF_COL = OFF_ORDER + MAXN * 2;          // u32 col[S*CW]
-constexpr int OFF_DEAD = OFF_COL + S * CW * 4;         // int dead[S]
-constexpr int LDS_BYTES = OFF_DEAD + S * 4;
+constexpr int NMS_MODE_MASK = 0xff;
 
 struct NmsArgs {
     const float4* boxes;
     const float* scores;
     const int* labels;
     const int* seg_count;
-    int num_seg, seg_stride, n_slots, n_pad, segments_sorted;
-    float thr_up;          // smallest float f with (double)f > iou_threshold; compare ovr >= thr_up
+    int num_seg, seg_stride, n_slots;
+    int lazy;              // 1: the segments are sorted and merged strip by strip; 0: `order` holds the global order
+    float thr_up;          // suppress when ovr >= thr_up (the threshold rule folded into one float, see od_batched_nms)
     int can_skip_zero;     // iou_threshold >= 0: a pair with zero intersection can never suppress
     int mode, max_keep;
-    float* ws;             // per image 7 * n_pad words: x1,y1,x2,y2,area (float), label, slot (int)
+    int* order;            // [batch, n_slots] slots in (score desc, slot asc) order          (lazy == 0)
+    int* kept_out;         // [batch, n_slots] kept slots in output order                      (max_keep > KC)
+    int* kept_cls;         // [batch, n_slots] kept slots in kept-list order beyond the LDS cache (max_keep > KC)
+    unsigned long long* stamps;
     long long* keep_idx;
     float4* out_boxes;
     float* out_scores;
@@ -83,7 +73,7 @@ __device__ __forceinline__ float intersection(const float4 i, const float4 j) {
     return w * h;
 }
 
-// ovr = inter / (iarea + jarea - inter);  (double)ovr > thr  <=>  ovr >= thr_up
+// ovr = inter / (iarea + jarea - inter);  suppressed  <=>  ovr >= thr_up
 __device__ __forceinline__ bool over_threshold_exact(float inter, float iarea, float jarea, float thr_up) {
     const float ovr = inter / ((iarea + jarea) - inter);
     return ovr >= thr_up;
@@ -106,30 +96,53 @@ __device__ __forceinline__ bool over_threshold(float inter, float iarea, float j
 }
 
 #ifdef OD_STAMPS
-#define STAMP(k) do { if (threadIdx.x == 0) stamps[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define STAMP(k) do { const int k__ = (k); if (threadIdx.x == 0 && k__ < 32) stamps[k__] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
 
+__device__ __forceinline__ unsigned long long nms_key(float score, int slot) {
+    return ((unsigned long long)ordered_key(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)slot);
+}
+
+// number of keys of the descending-sorted arr[0, len) that are greater than `key`
+__device__ __forceinline__ int count_greater(const unsigned long long* arr, int len, unsigned long long key) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (arr[mid] > key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[LDS_BYTES];
+    __shared__ uint32_t s_win[WSEG * S];                // the next S score keys of every segment (0: past the end)
+    __shared__ int s_wslot[WSEG * S];                   // their slots
+    __shared__ int s_wlab[WSEG * S];                    // their labels
+    __shared__ __attribute__((aligned(16))) float4 s_sbox[S];   // box of the strip's r-th candidate (as given)
+    __shared__ int s_sraw[S];                           // its label as given
+    __shared__ __attribute__((aligned(16))) float4 k_box[KC];   // kept boxes in kept-list order (strip, class, rank)
+    __shared__ float k_ar[KC];
+    __shared__ __attribute__((aligned(16))) int k_lab[KC];
+    __shared__ int s_kept_lds[KC];                      // kept slots in output order (max_keep <= KC)
+    __shared__ __attribute__((aligned(16))) float4 a_box[S];    // alive candidates of the strip, class order
+    __shared__ float a_ar[S];
+    __shared__ int a_lab[S];
+    __shared__ int a_slot[S];
+    __shared__ int a_rank[S];                           // rank of the alive candidate inside the strip (score order)
+    __shared__ unsigned int s_col[S * CW];
+    __shared__ int s_strip[S];                          // slot of the strip's r-th candidate (score order)
+    __shared__ __attribute__((aligned(16))) uint32_t s_ckey[S];   // its (class, rank) key
+    __shared__ int s_srank[WSEG * 16];                  // rank of every 16th window entry
+    __shared__ int s_crank[S];                          // its position in (class, rank) order
+    __shared__ int s_cpos[S];                           // inverse: rank of the candidate at class-order position c
+    __shared__ int s_flag[S];                           // A: dead; later: kept, by rank
     __shared__ int s_segpre[MAX_SEG + 1];
-    __shared__ int s_run[3][MAX_SEG + 1];     // merge rounds: [0] src start, [1] src length, [2] first chunk of pair
+    __shared__ int s_head[WSEG], s_taken[WSEG];
+    __shared__ unsigned long long s_keptw[SB];
     __shared__ int s_tmp[40];
-    __shared__ float s_ftmp[NT / 64];
-    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw + OFF_A);
-    unsigned long long* s_keys2 = reinterpret_cast<unsigned long long*>(s_raw + OFF_B);
-    float4* k_box = reinterpret_cast<float4*>(s_raw + OFF_KBOX);
-    float* k_ar = reinterpret_cast<float*>(s_raw + OFF_KAR);
-    int* k_lab = reinterpret_cast<int*>(s_raw + OFF_KLAB);
-    unsigned short* s_kept = reinterpret_cast<unsigned short*>(s_raw + OFF_KEPT);
-    float4* a_box = reinterpret_cast<float4*>(s_raw + OFF_ABOX);
-    float* a_ar = reinterpret_cast<float*>(s_raw + OFF_AAR);
-    int* a_lab = reinterpret_cast<int*>(s_raw + OFF_ALAB);
-    int* a_pos = reinterpret_cast<int*>(s_raw + OFF_APOS);
-    unsigned short* s_order = reinterpret_cast<unsigned short*>(s_raw + OFF_ORDER);
-    unsigned int* s_col = reinterpret_cast<unsigned int*>(s_raw + OFF_COL);
-    int* s_dead = reinterpret_cast<int*>(s_raw + OFF_DEAD);
+    __shared__ float s_ftmp[2 * (NT / 64)];
+    __shared__ int s_itmp[2 * (NT / 64)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -138,20 +151,16 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     const float* scores = a.scores + (long long)b * a.n_slots;
     const int* labels = a.labels ? a.labels + (long long)b * a.n_slots : nullptr;
     const int* segc = a.seg_count + (long long)b * a.num_seg;
-    float* sx1 = a.ws + (long long)b * 7 * a.n_pad;
-    float* sy1 = sx1 + a.n_pad;
-    float* sx2 = sy1 + a.n_pad;
-    float* sy2 = sx2 + a.n_pad;
-    float* sar = sy2 + a.n_pad;
-    int* slab = reinterpret_cast<int*>(sar + a.n_pad);
-    int* sslot = slab + a.n_pad;
+    const int* order = a.order ? a.order + (long long)b * a.n_slots : nullptr;
+    int* kept_out = (a.max_keep > KC) ? a.kept_out + (long long)b * a.n_slots : s_kept_lds;
+    int* kept_cls = (a.max_keep > KC) ? a.kept_cls + (long long)b * a.n_slots : nullptr;
 #ifdef OD_STAMPS
-    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(a.ws + (long long)gridDim.x * 7 * a.n_pad) + blockIdx.x * 32;
+    unsigned long long* stamps = a.stamps + blockIdx.x * 32;
     int stamp_i = 4;
 #endif
     STAMP(0);
 
-    // ---- 1. keys, valid count, max coordinate ------------------------------------------------------
+    // ---- 1. valid count --------------------------------------------------------------------------------------
     if (tid == 0) {
         int acc = 0;
         for (int s = 0; s < a.num_seg; ++s) {
@@ -163,150 +172,101 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
         s_segpre[a.num_seg] = acc;
     }
     __syncthreads();
+    // ---- 2. segment heads; the first windows are requested before anything waits for them ----------------------
+    const int nseg = a.lazy ? a.num_seg : 1;
+    if (tid < WSEG) { s_head[tid] = 0; s_taken[tid] = 0; }
+    if (tid == 0) { s_tmp[0] = 0; s_tmp[1] = 0; }   // [0] = kept count, [1] = done flag
+    __syncthreads();
     const int n_valid = s_segpre[a.num_seg];
-    float maxc = -__builtin_inff();
-    for (int i = tid; i < a.n_pad; i += NT) {
-        unsigned long long key = 0ull;
-        if (i < a.n_slots) {
-            const int seg = i / a.seg_stride;
-            const int r = i - seg * a.seg_stride;
-            if (r < s_segpre[seg + 1] - s_segpre[seg]) {
-                key = ((unsigned long long)ordered_key(scores[i]) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)i);
-                const float4 bx = boxes[i];
-                maxc = fmaxf(maxc, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+
+    // Window entry e = segment * S + i of the strip that starts at the current heads.  A thread owns the entries
+    // tid and tid + NT; their scores and labels are requested one strip ahead (the loads are in flight while the
+    // previous strip is processed) and written to LDS at the top of the strip.
+    float pf_score[2];
+    int pf_slot[2], pf_lab[2];
+    auto prefetch_windows = [&]() {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * NT;
+            pf_slot[u] = -1;
+            pf_score[u] = 0.0f;
+            pf_lab[u] = 0;
+            if (e < nseg * S) {
+                const int l = e >> 8, i = e & (S - 1);
+                const int len = a.lazy ? (s_segpre[l + 1] - s_segpre[l]) : n_valid;
+                const int pos = s_head[l] + i;
+                if (pos < len) {
+                    const int slot = a.lazy ? l * a.seg_stride + pos : order[pos];
+                    pf_slot[u] = slot;
+                    pf_score[u] = scores[slot];
+                    if (labels) pf_lab[u] = labels[slot];
+                }
             }
         }
-        s_keys[i] = key;
-    }
-    maxc = wave_fmax_all(maxc);
-    if (lane == 0) s_ftmp[wave] = maxc;
-    __syncthreads();
-    maxc = s_ftmp[0];
-#pragma unroll
-    for (int w = 1; w < NT / 64; ++w) maxc = fmaxf(maxc, s_ftmp[w]);
+    };
+    prefetch_windows();
 
-    int mode = a.mode;
+    int mode = a.mode & NMS_MODE_MASK;
     if (mode == OD_NMS_AUTO_CPU) mode = (4 * n_valid > 4000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
     if (mode == OD_NMS_AUTO_GPU) mode = (4 * n_valid > 20000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
     const bool vanilla = (mode == OD_NMS_VANILLA) && labels != nullptr;
     const bool trick = (mode == OD_NMS_TRICK) && labels != nullptr;
+    float step = 0.0f;                // offsets = labels.to(boxes) * (boxes.max() + 1)
+    bool independent = vanilla;       // boxes of different classes never suppress each other
+    bool one_class = labels == nullptr;
+    int label_base = 0;               // smallest label of the image
+    bool packable = false;            // label - label_base fits in 23 bits: (class, rank) sorts as one 32-bit key
+    if (labels) {
+        float maxc = -__builtin_inff(), minc = __builtin_inff();
+        int maxl = (int)0x80000000, minl = 0x7fffffff;
+        for (int i0 = tid; i0 < a.n_slots; i0 += 4 * NT) {       // the loads of four slots are in flight together
+            float4 bx[4];
+            int lab[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                const int ic = i < a.n_slots ? i : 0;
+                const int seg = ic / a.seg_stride;
+                const int r = ic - seg * a.seg_stride;
+                ok[u] = i < a.n_slots && r < s_segpre[seg + 1] - s_segpre[seg];
+                bx[u] = boxes[ic];
+                lab[u] = labels[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (ok[u]) {
+                    maxc = fmaxf(maxc, fmaxf(fmaxf(bx[u].x, bx[u].y), fmaxf(bx[u].z, bx[u].w)));
+                    minc = fminf(minc, fminf(fminf(bx[u].x, bx[u].y), fminf(bx[u].z, bx[u].w)));
+                    maxl = lab[u] > maxl ? lab[u] : maxl;
+                    minl = lab[u] < minl ? lab[u] : minl;
+                }
+            }
+        }
+        maxc = wave_fmax_all(maxc);
+        minc = wave_fmin_all(minc);
+        maxl = (int)(wave_umax_all((uint32_t)maxl ^ 0x80000000u) ^ 0x80000000u);
+        minl = (int)(~wave_umax_all(~((uint32_t)minl ^ 0x80000000u)) ^ 0x80000000u);
+        if (lane == 0) { s_ftmp[wave] = maxc; s_ftmp[NT / 64 + wave] = minc; s_itmp[wave] = maxl; s_itmp[NT / 64 + wave] = minl; }
+        __syncthreads();
+        maxc = s_ftmp[0]; minc = s_ftmp[NT / 64]; maxl = s_itmp[0]; minl = s_itmp[NT / 64];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) {
+            maxc = fmaxf(maxc, s_ftmp[w]);
+            minc = fminf(minc, s_ftmp[NT / 64 + w]);
+            maxl = s_itmp[w] > maxl ? s_itmp[w] : maxl;
+            minl = s_itmp[NT / 64 + w] < minl ? s_itmp[NT / 64 + w] : minl;
+        }
+        step = maxc + 1.0f;
+        // A box of class c ends at or below max + c*step, a box of class c' > c starts at or above c'*step; with
+        // max + c*step <= c'*step after rounding (ensured by 2*c'*step*2^-24 <= 1), non-negative coordinates and
+        // labels, the two cannot intersect, their overlap is 0 (or NaN) and never exceeds a threshold >= 0.
+        if (trick) independent = a.can_skip_zero && minc >= 0.0f && minl >= 0 && ((float)maxl * step <= 8388608.0f);
+        one_class = (minl == maxl);
+        label_base = minl;
+        packable = ((uint32_t)maxl - (uint32_t)minl) < (1u << 23);
+    }
     STAMP(1);
-
-    // ---- 2. order: s_order[rank] = slot, ranks by (score desc, slot asc) --------------------------
-    if (a.segments_sorted && a.n_slots <= MERGE_MAX) {
-        // merge-path tree over the pre-sorted segments: each round merges adjacent runs pairwise
-        unsigned long long* src = s_keys;
-        unsigned long long* dst = s_keys2;
-        int nruns = a.num_seg;
-        if (tid < nruns) { s_run[0][tid] = tid * a.seg_stride; s_run[1][tid] = s_segpre[tid + 1] - s_segpre[tid]; }
-        __syncthreads();
-        const int CH = (n_valid + NT - 1) / NT > 0 ? (n_valid + NT - 1) / NT : 1;   // outputs per chunk
-        while (nruns > 1) {
-            const int npairs = (nruns + 1) >> 1;
-            if (tid == 0) {
-                int chunk = 0;
-                for (int p = 0; p < npairs; ++p) {
-                    const int la = s_run[1][2 * p];
-                    const int lb = (2 * p + 1 < nruns) ? s_run[1][2 * p + 1] : 0;
-                    s_run[2][p] = chunk;
-                    chunk += (la + lb + CH - 1) / CH;
-                }
-                s_run[2][npairs] = chunk;
-            }
-            __syncthreads();
-            const int nchunks = s_run[2][npairs];
-            for (int ch = tid; ch < nchunks; ch += NT) {
-                int p = 0;
-                while (p + 1 < npairs && ch >= s_run[2][p + 1]) ++p;
-                const int sa = s_run[0][2 * p], na = s_run[1][2 * p];
-                const bool hasb = 2 * p + 1 < nruns;
-                const int sb = hasb ? s_run[0][2 * p + 1] : 0, nb = hasb ? s_run[1][2 * p + 1] : 0;
-                int outbase = 0;
-                for (int q = 0; q < p; ++q)
-                    outbase += s_run[1][2 * q] + ((2 * q + 1 < nruns) ? s_run[1][2 * q + 1] : 0);
-                const int k0 = (ch - s_run[2][p]) * CH;
-                const int k1 = (k0 + CH < na + nb) ? k0 + CH : na + nb;
-                // co-rank: i = number of A elements among the first k0 outputs
-                int lo = k0 - nb > 0 ? k0 - nb : 0, hi = k0 < na ? k0 : na;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (src[sa + mid] > src[sb + (k0 - mid - 1)]) lo = mid + 1; else hi = mid;
-                }
-                int i = lo, j = k0 - lo;
-                for (int k = k0; k < k1; ++k) {
-                    const unsigned long long va = (i < na) ? src[sa + i] : 0ull;
-                    const unsigned long long vb = (j < nb) ? src[sb + j] : 0ull;
-                    const bool takea = (j >= nb) || (i < na && va > vb);
-                    dst[outbase + k] = takea ? va : vb;
-                    i += takea ? 1 : 0;
-                    j += takea ? 0 : 1;
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int acc = 0;
-                for (int p = 0; p < npairs; ++p) {
-                    const int len = s_run[1][2 * p] + ((2 * p + 1 < nruns) ? s_run[1][2 * p + 1] : 0);
-                    s_run[0][p] = acc;
-                    s_run[1][p] = len;
-                    acc += len;
-                }
-            }
-            __syncthreads();
-            nruns = npairs;
-            unsigned long long* t = src; src = dst; dst = t;
-        }
-        const int start = s_run[0][0];
-        for (int p = tid; p < n_valid; p += NT) s_order[p] = (unsigned short)(0xFFFFFFFFu - (uint32_t)src[start + p]);
-        __syncthreads();
-    } else {
-        // bitonic sort of the keys, descending; each thread owns n_pad/2/NT disjoint pairs per stage,
-        // loads them all, then stores (the LDS latency is paid once per stage, not once per pair)
-        constexpr int PQ = MAXN / 2 / NT;
-        for (int k = 2; k <= a.n_pad; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                unsigned long long x[PQ], y[PQ];
-                int lo[PQ];
-#pragma unroll
-                for (int q = 0; q < PQ; ++q) {
-                    const int pr = tid + q * NT;                          // pair index
-                    lo[q] = ((pr & ~(j - 1)) << 1) | (pr & (j - 1));      // insert a 0 bit at log2(j)
-                    const bool on = pr < (a.n_pad >> 1);
-                    x[q] = on ? s_keys[lo[q]] : 0ull;
-                    y[q] = on ? s_keys[lo[q] | j] : 0ull;
-                }
-#pragma unroll
-                for (int q = 0; q < PQ; ++q) {
-                    const int pr = tid + q * NT;
-                    const bool desc = (lo[q] & k) == 0;
-                    if (pr < (a.n_pad >> 1) && ((x[q] < y[q]) == desc)) { s_keys[lo[q]] = y[q]; s_keys[lo[q] | j] = x[q]; }
-                }
-                __syncthreads();
-            }
-        }
-        for (int p = tid; p < n_valid; p += NT) s_order[p] = (unsigned short)(0xFFFFFFFFu - (uint32_t)s_keys[p]);
-        __syncthreads();
-    }
-    STAMP(2);
-
-    // ---- 3. gather sorted boxes into the SoA workspace --------------------------------------------
-    const float step = maxc + 1.0f;   // offsets = labels.to(boxes) * (boxes.max() + 1)
-    for (int p = tid; p < n_valid; p += NT) {
-        const int slot = (int)s_order[p];
-        float4 bx = boxes[slot];
-        const int lab = labels ? labels[slot] : 0;
-        if (trick) {
-            const float off = (float)lab * step;
-            bx.x += off; bx.y += off; bx.z += off; bx.w += off;
-        }
-        sx1[p] = bx.x; sy1[p] = bx.y; sx2[p] = bx.z; sy2[p] = bx.w;
-        sar[p] = (bx.z - bx.x) * (bx.w - bx.y);
-        slab[p] = lab;
-        sslot[p] = slot;
-    }
-    if (tid == 0) { s_tmp[0] = 0; s_tmp[1] = 0; }   // [0] = kept count, [1] = done flag
-    __syncthreads();
-    STAMP(3);
 
     const int max_keep = a.max_keep < n_valid ? a.max_keep : n_valid;
     ThrBand thr;
@@ -315,85 +275,197 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     thr.hi = a.thr_up * (1.0f + 1e-5f);
     thr.usable = (a.thr_up > 1e-30f) && (a.thr_up < 1e30f);
     const bool can_skip = a.can_skip_zero != 0;
+    const bool by_class = independent && !one_class;   // only boxes of equal label can suppress each other
+    const bool group = by_class && packable;           // candidates are grouped by class inside a strip
 
-    // ---- 4. strips ------------------------------------------------------------------------------------
+    // ---- 3. strips ------------------------------------------------------------------------------------------
+    int nk_cls = 0;                                    // entries of the kept list (== kept count until the cap binds)
     for (int s0 = 0, SL = S; s0 < n_valid && max_keep > 0; s0 += SL) {
         const int nk = s_tmp[0];
-        // strip length: the full 256 while many boxes are still wanted, shorter (a multiple of 64) once
-        // only a few are missing (64 or 128), so that the last strip does not test 256 candidates to keep a handful
+        // strip length: the full 256 while many boxes are still wanted, shorter (64 or 128) once only a few are
+        // missing, so that the last strip does not test 256 candidates to keep a handful
         {
             const int want = max_keep - nk;
             const int target = want + (want >> 1);
-            SL = target <= 64 ? 64 : (target <= 128 ? 128 : S);      // power of two: c = tid & (SL - 1)
+            SL = target <= 64 ? 64 : (target <= 128 ? 128 : S);      // power of two
         }
+        const int slog = SL == 64 ? 6 : (SL == 128 ? 7 : 8);
+        const int ns = (n_valid - s0) < SL ? (n_valid - s0) : SL;    // candidates of this strip
         const int parts = NT / SL;
-        if (tid < S) s_dead[tid] = 0;
-        for (int i = tid; i < S * CW; i += NT) s_col[i] = 0u;
-        __syncthreads();
 
-        // -- A: against the kept list ------------------------------------------------------------------
+        // -- windows: the next S keys of every segment (requested during the previous strip) -------------------
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = tid + u * NT;
+            if (e < nseg * S) {
+                // score key of a valid entry: at least 1 (only the two lowest NaN patterns share a key)
+                const uint32_t sk = ordered_key(pf_score[u]);
+                s_win[e] = pf_slot[u] >= 0 ? (sk > 1u ? sk : 1u) : 0u;
+                s_wslot[e] = pf_slot[u];
+                s_wlab[e] = pf_lab[u];
+            }
+        }
+        for (int i = tid; i < S * CW; i += NT) s_col[i] = 0u;
+        if (tid < S) { s_flag[tid] = 0; s_crank[tid] = 0; s_ckey[tid] = 0xFFFFFFFFu; }
+        __syncthreads();
+#ifdef OD_STAMPS_FINE
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
+        // -- rank inside the union of the windows; rank < ns makes the strip ----------------------------------------
+        // Ranks grow along a window, so most entries are ruled out by a sample: two waves rank every 16th entry of
+        // every window; an entry whose preceding sample already has rank >= ns is not in the strip and skips the
+        // search.  About ns + 16 * nseg entries remain, in whole waves at the head of every window.
+        // Entry (window l, position i, score key k) is preceded by the entries of window o with a greater score key
+        // and, for o < l, by those with the same key (equal scores: lower slot first, and slots grow with the
+        // segment).  The binary searches in all windows advance together: one LDS round trip per level.
+        auto window_rank = [&](int l, int i, uint32_t k) -> int {
+            int cnt[WSEG];
+            uint32_t bar[WSEG];                                  // entries above bar[o] precede (k >= 1)
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) { cnt[o] = 0; bar[o] = k - (o < l ? 1u : 0u); }
+            for (int st = S >> 1; st >= 1; st >>= 1) {
+                uint32_t v[WSEG];
+#pragma unroll
+                for (int o = 0; o < WSEG; ++o) v[o] = s_win[o * S + cnt[o] + st - 1];
+#pragma unroll
+                for (int o = 0; o < WSEG; ++o) cnt[o] += (v[o] > bar[o]) ? st : 0;
+            }
+            int rank = i;
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) {                     // the search stops at S - 1: the last entry decides
+                cnt[o] += (cnt[o] == S - 1 && s_win[o * S + S - 1] > bar[o]) ? 1 : 0;
+                rank += (o < nseg && o != l) ? cnt[o] : 0;
+            }
+            return rank;
+        };
+        if (nseg > 1) {
+            if (tid < nseg * 16) {
+                const int l = tid >> 4, i = ((tid & 15) << 4) | 15;
+                const uint32_t key = s_win[l * S + i];
+                s_srank[tid] = key != 0u ? window_rank(l, i, key) : 0x7fffffff;
+            }
+            __syncthreads();
+        }
+#ifdef OD_STAMPS_FINE
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
+        // thread = (window tid / 128, entry tid % 128); the upper halves of the windows take a second pass, which
+        // runs only if a window contributes more than 128 candidates
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int l = tid >> 7, i = (tid & 127) + u * 128;
+            const int e = l * S + i;
+            uint32_t key = (l < nseg && i < ns) ? s_win[e] : 0u;
+            if (nseg > 1 && key != 0u && i >= 16 && s_srank[(l << 4) + (i >> 4) - 1] >= ns) key = 0u;
+            if (__ballot(key != 0u) == 0ull) continue;
+            const int rank = nseg > 1 ? window_rank(l, i, key) : i;
+            if (key != 0u && rank < ns) {
+                const int slot = s_wslot[e];
+                const int lab = s_wlab[e];
+                s_strip[rank] = slot;
+                s_sraw[rank] = lab;
+                if (group) s_ckey[rank] = ((uint32_t)(lab - label_base) << 8) | (uint32_t)rank;
+                atomicMax(&s_taken[l], i + 1);
+            }
+        }
+        __syncthreads();
+#ifdef OD_STAMPS_FINE
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
+        if (tid < nseg) { s_head[tid] += s_taken[tid]; s_taken[tid] = 0; }
+        // the boxes of the strip are requested now and stored after the next loop
+        float4 my_box = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < ns) my_box = boxes[s_strip[tid]];
+        // -- position of every candidate in (class, rank) order: number of smaller (class, rank) keys --------------
+        if (group) {
+            const int r = tid & (S - 1), quarter = tid >> 8;
+            const uint32_t mine = s_ckey[r];
+            const uint2* keys2 = reinterpret_cast<const uint2*>(s_ckey + quarter * (SL >> 2));
+            int cnt = 0;
+#pragma unroll 8
+            for (int k = 0; k < (SL >> 3); ++k) {
+                const uint2 kk = keys2[k];
+                cnt += (kk.x < mine ? 1 : 0) + (kk.y < mine ? 1 : 0);
+            }
+            if (r < ns && cnt) atomicAdd(&s_crank[r], cnt);
+        }
+        if (tid < ns) s_sbox[tid] = my_box;
+        __syncthreads();
+#ifdef OD_STAMPS_FINE
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
+        prefetch_windows();                                  // for the next strip: the heads are final
+        if (tid < ns) s_cpos[group ? s_crank[tid] : tid] = tid;
+        __syncthreads();
+#ifdef OD_STAMPS
+        if (stamp_i < 30) STAMP(stamp_i++);
+#endif
+
+        // -- A: against the kept list ------------------------------------------------------------------------------
         const int c = tid & (SL - 1);
-        const int part = tid / SL;
-        const int p = s0 + c;
-        const bool valid = p < n_valid;
-        const int pp = valid ? p : n_valid - 1;
-        const float4 jb = make_float4(sx1[pp], sy1[pp], sx2[pp], sy2[pp]);
-        const float jar = sar[pp];
-        const int jlab = slab[pp];
+        const int part = tid >> slog;
+        const bool valid = c < ns;
+        const int rnk = s_cpos[valid ? c : 0];
+        const int slot = s_strip[rnk];
+        const int jraw = s_sraw[rnk];
+        const int jlab = by_class ? jraw : 0;                // labels are compared only when classes cannot interact
+        float4 jb = s_sbox[rnk];
+        if (trick) {
+            const float off = (float)jraw * step;
+            jb.x += off; jb.y += off; jb.z += off; jb.w += off;
+        }
+        const float jar = (jb.z - jb.x) * (jb.w - jb.y);
         {
             bool dead = false;
-            const int nk_lds = nk < KC ? nk : KC;
+            const int nk_lds = nk_cls < KC ? nk_cls : KC;
             for (int e0 = part * 4; e0 < nk_lds; e0 += parts * 4) {
-                float inter[4], iar[4];
-                bool anypos = false;
+                const int4 kl = *reinterpret_cast<const int4*>(&k_lab[e0]);
+                const int kls[4] = {kl.x, kl.y, kl.z, kl.w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int e = (e0 + u < nk_lds) ? e0 + u : nk_lds - 1;     // tail repeats the last kept box
-                    inter[u] = intersection(k_box[e], jb);
-                    iar[u] = k_ar[e];
-                    anypos = anypos || (inter[u] > 0.0f);
-                }
-                if (can_skip && __ballot(anypos) == 0) continue;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int e = (e0 + u < nk_lds) ? e0 + u : nk_lds - 1;
-                    bool sup = over_threshold(inter[u], iar[u], jar, thr);
-                    if (vanilla) sup = sup && (k_lab[e] == jlab);
-                    dead = dead || sup;
+                    const bool same = (e0 + u < nk_lds) && (kls[u] == jlab);
+                    if (__ballot(same) == 0ull) continue;                     // no candidate of this wave has that class
+                    const float inter = intersection(k_box[e0 + u], jb);
+                    if (can_skip && __ballot(same && inter > 0.0f) == 0ull) continue;
+                    const bool sup = over_threshold(inter, k_ar[e0 + u], jar, thr);
+                    dead = dead || (sup && same);
                 }
             }
-            // kept boxes beyond the LDS cache come from the workspace, four at a time so that their loads overlap
-            for (int e0 = KC + part * 4; e0 < nk; e0 += parts * 4) {
+            // kept boxes beyond the LDS cache come from memory, four at a time so that their loads overlap
+            for (int e0 = KC + part * 4; e0 < nk_cls; e0 += parts * 4) {
                 float4 kb[4];
-                float kar[4];
                 int klab[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int kp = s_kept[(e0 + u < nk) ? e0 + u : nk - 1];     // tail repeats the last kept box
-                    kb[u] = make_float4(sx1[kp], sy1[kp], sx2[kp], sy2[kp]);
-                    kar[u] = sar[kp];
-                    klab[u] = slab[kp];
+                    const int ks = kept_cls[(e0 + u < nk_cls) ? e0 + u : nk_cls - 1];     // tail repeats the last kept box
+                    kb[u] = boxes[ks];
+                    const int raw = labels ? labels[ks] : 0;
+                    klab[u] = by_class ? raw : 0;
+                    if (trick) {
+                        const float off = (float)raw * step;
+                        kb[u].x += off; kb[u].y += off; kb[u].z += off; kb[u].w += off;
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const float inter = intersection(kb[u], jb);
-                    bool sup = over_threshold_exact(inter, kar[u], jar, thr.up);
-                    if (vanilla) sup = sup && (klab[u] == jlab);
-                    dead = dead || sup;
+                    const float kar = (kb[u].z - kb[u].x) * (kb[u].w - kb[u].y);
+                    const bool sup = over_threshold_exact(inter, kar, jar, thr.up);
+                    dead = dead || (sup && klab[u] == jlab);
                 }
             }
-            if (dead && valid) s_dead[c] = 1;
+            if (dead && valid) s_flag[c] = 1;
         }
         __syncthreads();
 #ifdef OD_STAMPS
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
 
-        // -- compact the alive candidates of the strip into LDS (order preserved) ---------------------
+        // -- compact the alive candidates of the strip into LDS (class order preserved) ---------------------------
         bool alive = false;
         int wrank = 0;
         if (tid < SL) {
-            alive = valid && (s_dead[tid] == 0);
+            alive = valid && (s_flag[tid] == 0);
             const uint64_t bal = __ballot(alive);
             if (lane == 0) s_tmp[8 + wave] = __popcll(bal);
             wrank = mbcnt(bal);
@@ -410,54 +482,45 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
             }
             if (alive) {
                 const int q = pre + wrank;
-                a_box[q] = jb; a_ar[q] = jar; a_lab[q] = jlab; a_pos[q] = p;
+                a_box[q] = jb; a_ar[q] = jar; a_lab[q] = jlab; a_slot[q] = slot; a_rank[q] = rnk;
             }
         }
+        if (tid < S) s_flag[tid] = 0;                        // from here on: kept, indexed by rank
         __syncthreads();
         const int nab = (na + 63) >> 6;
 #ifdef OD_STAMPS
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
 
-        // -- B: pairwise bits among alive candidates, 16 rows x 64 columns per work item --------------
+        // -- B: every alive candidate against the earlier alive candidates of its class ---------------------------
+        // thread = (column j, quarter of the rows); the waves of one quarter take the column blocks in rotated
+        // order so that every SIMD receives short and long columns
         {
-            const int n_tiles = nab * (nab + 1) / 2;
-            for (int item = wave; item < n_tiles * 4; item += NT / 64) {
-                const int tile = item >> 2, quarter = item & 3;
-                int rb = 0, t = tile;
-                while (t >= nab - rb) { t -= nab - rb; ++rb; }   // row block rb, column block cb >= rb
-                const int cb = rb + t;
-                const int col = cb * 64 + lane;
-                const bool cvalid = col < na;
-                const int cq = cvalid ? col : na - 1;
-                const float4 cbx = a_box[cq];
-                const float car = a_ar[cq];
-                const int clab = a_lab[cq];
-                const int row0 = rb * 64 + quarter * 16;
-                const int rcnt = (na - row0) < 16 ? (na - row0) : 16;
-                unsigned int bits = 0u;
-                for (int i0 = 0; i0 < rcnt; i0 += 4) {
-                    float inter[4], iar[4];
-                    bool anypos = false;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = (row0 + i0 + u < na) ? row0 + i0 + u : na - 1;   // masked below
-                        inter[u] = intersection(a_box[r], cbx);
-                        iar[u] = a_ar[r];
-                        anypos = anypos || (inter[u] > 0.0f);
-                    }
-                    if (can_skip && __ballot(anypos) == 0) continue;
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + u;
-                        const int r = (row0 + i < na) ? row0 + i : na - 1;
-                        bool sup = over_threshold(inter[u], iar[u], car, thr);
-                        if (vanilla) sup = sup && (a_lab[r] == clab);
-                        sup = sup && (i < rcnt) && (row0 + i < col);
-                        bits |= sup ? (1u << i) : 0u;
-                    }
-                }
-                if (cvalid && bits) atomicOr(&s_col[col * CW + rb * 2 + (quarter >> 1)], bits << ((quarter & 1) * 16));
+            const int bpart = wave >> 2;                          // rows i with (i - run start) % 4 == bpart
+            const int j = (((wave + bpart) & 3) << 6) | lane;
+            const bool jv = j < na;
+            const int jq = jv ? j : 0;
+            const float4 cbx = a_box[jq];
+            const float car = a_ar[jq];
+            const int mine = a_lab[jq];
+            // rows i = j - 1 - bpart, j - 5 - bpart, ...: with grouped candidates the walk ends where the class ends
+            // (earlier candidates of the strip have smaller classes); two rows per step, their reads together
+            bool open = jv;                                       // this column may still meet rows of its class
+            for (int i = j - 1 - bpart; __ballot(open && i >= 0) != 0ull; i -= 8) {
+                const int i2 = i - 4;
+                const bool in1 = open && i >= 0, in2 = open && i2 >= 0;
+                const int q1 = in1 ? i : 0, q2 = in2 ? i2 : 0;
+                const float4 r1 = a_box[q1], r2 = a_box[q2];
+                const float ar1 = a_ar[q1], ar2 = a_ar[q2];
+                const int l1 = a_lab[q1], l2 = a_lab[q2];
+                const bool on1 = in1 && l1 == mine, on2 = in2 && l2 == mine;
+                if (group) open = open && on2;                   // sorted by class: a different class ends the walk
+                const float inter1 = intersection(r1, cbx), inter2 = intersection(r2, cbx);
+                if (can_skip && __ballot((on1 && inter1 > 0.0f) || (on2 && inter2 > 0.0f)) == 0ull) continue;
+                const bool sup1 = over_threshold(inter1, ar1, car, thr) && on1;
+                const bool sup2 = over_threshold(inter2, ar2, car, thr) && on2;
+                if (sup1) atomicOr(&s_col[j * CW + (i >> 5)], 1u << (i & 31));
+                if (sup2) atomicOr(&s_col[j * CW + (i2 >> 5)], 1u << (i2 & 31));
             }
         }
         __syncthreads();
@@ -465,16 +528,14 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
 
-        // -- C: resolve the strip in order (one wave) ---------------------------------------------------
+        // -- C: resolve the strip in class order (one wave) ---------------------------------------------------------
         if (wave == 0) {
             unsigned long long keptw[SB];
 #pragma unroll
             for (int i = 0; i < SB; ++i) keptw[i] = 0ull;
-            int nkept = nk;
-            bool done = false;
 #pragma unroll
             for (int blk = 0; blk < SB; ++blk) {
-                if (blk < nab && !done) {
+                if (blk < nab) {
                     const int col = blk * 64 + lane;
                     const bool cvalid = col < na;
                     const unsigned int* cw = &s_col[(cvalid ? col : 0) * CW];
@@ -495,17 +556,54 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
                         K = K2;
                     }
                     keptw[blk] = K;
-                    const bool kept = (K >> lane) & 1ull;
-                    const int pos = nkept + mbcnt(K);
-                    if (kept && pos < max_keep) {
-                        s_kept[pos] = (unsigned short)a_pos[col];
-                        if (pos < KC) { k_box[pos] = a_box[col]; k_ar[pos] = a_ar[col]; k_lab[pos] = a_lab[col]; }
-                    }
-                    nkept += __popcll(K);
-                    if (nkept >= max_keep) { nkept = max_keep; done = true; }
                 }
             }
-            if (lane == 0) { s_tmp[0] = nkept; s_tmp[1] = done ? 1 : 0; }
+            if (lane == 0) {
+#pragma unroll
+                for (int i = 0; i < SB; ++i) s_keptw[i] = keptw[i];
+            }
+        }
+        __syncthreads();
+        // -- append: kept list in class order, output list in score order ---------------------------------------
+        int kept_total = 0;
+        {
+            int before = 0;                                  // kept columns before this thread's column
+            bool kept = false;
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const unsigned long long m = s_keptw[i];
+                kept_total += __popcll(m);
+                if (i < (tid >> 6)) before += __popcll(m);
+                else if (i == (tid >> 6)) { before += __popcll(m & ((1ull << lane) - 1ull)); kept = (m >> lane) & 1ull; }
+            }
+            if (tid < na && kept) {
+                const int q = nk_cls + before;
+                if (q < KC) { k_box[q] = a_box[tid]; k_ar[q] = a_ar[tid]; k_lab[q] = a_lab[tid]; }
+                else if (kept_cls) kept_cls[q] = a_slot[tid];
+                s_flag[a_rank[tid]] = 1;
+            }
+        }
+        __syncthreads();
+        if (tid < SL) {
+            const bool kept = s_flag[tid] != 0;
+            const uint64_t bal = __ballot(kept);
+            if (lane == 0) s_tmp[16 + wave] = __popcll(bal);
+            wrank = mbcnt(bal);
+            alive = kept;
+        }
+        __syncthreads();
+        if (tid < SL && alive) {
+            int pre = 0;
+#pragma unroll
+            for (int w = 0; w < SB; ++w) if (w < wave && w * 64 < SL) pre += s_tmp[16 + w];
+            const int pos = nk + pre + wrank;
+            if (pos < max_keep) kept_out[pos] = s_strip[tid];
+        }
+        nk_cls += kept_total;
+        if (tid == 0) {
+            int t = nk + kept_total;
+            if (t >= max_keep) { t = max_keep; s_tmp[1] = 1; }
+            s_tmp[0] = t;
         }
         __syncthreads();
 #ifdef OD_STAMPS
@@ -516,12 +614,12 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     __syncthreads();
     STAMP(30);
 
-    // ---- 5. outputs -----------------------------------------------------------------------------------
+    // ---- 4. outputs -----------------------------------------------------------------------------------
     const int nk = s_tmp[0];
     for (int k = tid; k < a.max_keep; k += NT) {
         const long long o = (long long)b * a.max_keep + k;
         if (k < nk) {
-            const int slot = sslot[s_kept[k]];
+            const int slot = kept_out[k];
             a.out_boxes[o] = boxes[slot];
             a.out_scores[o] = scores[slot];
             if (a.out_labels) a.out_labels[o] = labels ? (long long)labels[slot] : 0ll;
@@ -538,6 +636,43 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     }
     if (tid == 0) a.out_count[b] = nk;
     STAMP(31);
+}
+
+// Global order of unsorted candidates (or of more than WSEG segments): rank of a candidate = number of valid
+// candidates with a greater key (score, then lower slot).  Keys are unique, so the ranks are a permutation:
+// order[rank] = slot.  O(n^2) comparisons spread over the whole chip: 256 candidates per workgroup against all
+// candidates, staged through LDS in tiles of 1024.
+constexpr int OT = 256;
+constexpr int OTILE = 1024;
+__global__ __launch_bounds__(OT) void nms_order_kernel(const float* __restrict__ scores_all, const int* __restrict__ seg_count,
+                                                       int num_seg, int seg_stride, int n_slots, int* __restrict__ order_all) {
+    __shared__ unsigned long long s_key[OTILE];
+    __shared__ int s_cnt[MAX_SEG];
+    const int b = blockIdx.y;
+    const float* scores = scores_all + (long long)b * n_slots;
+    int* order = order_all + (long long)b * n_slots;
+    if ((int)threadIdx.x < num_seg) {
+        int c = seg_count[(long long)b * num_seg + threadIdx.x];
+        s_cnt[threadIdx.x] = c < 0 ? 0 : (c > seg_stride ? seg_stride : c);
+    }
+    __syncthreads();
+    auto key_of = [&](int i) -> unsigned long long {
+        if (i >= n_slots) return 0ull;
+        const int seg = i / seg_stride;
+        return (i - seg * seg_stride < s_cnt[seg]) ? nms_key(scores[i], i) : 0ull;
+    };
+    const int me = blockIdx.x * OT + threadIdx.x;
+    const unsigned long long mine = key_of(me);
+    int rank = 0;
+    for (int t0 = 0; t0 < n_slots; t0 += OTILE) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < OTILE; i += OT) s_key[i] = key_of(t0 + i);
+        __syncthreads();
+        const int lim = (n_slots - t0) < OTILE ? (n_slots - t0) : OTILE;
+#pragma unroll 8
+        for (int i = 0; i < lim; ++i) rank += (s_key[i] > mine) ? 1 : 0;
+    }
+    if (mine != 0ull) order[rank] = me;
 }
 
 // one thread per padded detection slot: six floats of the message row; thread 0 of an image appends the count
@@ -558,20 +693,17 @@ __global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ bo
     if (k == 0) row[6ll * max_det] = (float)counts[b];
 }
 
-int next_pow2(int v) {
-    int p = 64;
-    while (p < v) p <<= 1;
-    return p;
-}
-
 }  // namespace
 
+static size_t nms_align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// workspace: order | kept_out | kept_cls (int32 [batch, n_slots] each) | time stamps of a debug build
 extern "C" size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride) {
     if (batch < 0 || num_seg < 1 || seg_stride < 1) return 0;
     long long n = (long long)num_seg * seg_stride;
-    if (n > MAXN) return 0;
-    size_t b = (size_t)batch * 7 * (size_t)next_pow2((int)n) * 4 + (size_t)batch * 256;   // + debug stamps
-    return (b + 255) & ~(size_t)255;
+    if (n > MAXN || num_seg > MAX_SEG) return 0;
+    const size_t part = nms_align256((size_t)batch * (size_t)n * sizeof(int));
+    return 3 * part + nms_align256((size_t)batch * 256);
 }
 
 static int batched_nms_launch(const float* boxes, const float* scores, const int32_t* labels,
@@ -583,10 +715,13 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
     if (batch < 0 || num_seg < 1 || seg_stride < 1 || max_keep < 0) return OD_ERR_ARG;
     if (batch == 0) return OD_OK;
     if (!boxes || !scores || !seg_count || !out_boxes || !out_scores || !out_count || !workspace) return OD_ERR_ARG;
-    if (num_seg > MAX_SEG || (long long)num_seg * seg_stride > MAXN) return OD_ERR_LIMIT;
-    if (mode < OD_NMS_TRICK || mode > OD_NMS_AUTO_GPU) return OD_ERR_ARG;
-    if (((uintptr_t)boxes & 15) || ((uintptr_t)out_boxes & 15)) return OD_ERR_ARG;
+    if (num_seg > MAX_SEG || (long long)num_seg * seg_stride > MAXN || batch > 65535) return OD_ERR_LIMIT;
+    const int rule = mode & ~NMS_MODE_MASK;
+    const int base_mode = mode & NMS_MODE_MASK;
+    if (base_mode < OD_NMS_TRICK || base_mode > OD_NMS_AUTO_GPU || (rule & ~OD_NMS_THRESHOLD_FLOAT)) return OD_ERR_ARG;
+    if (((uintptr_t)boxes & 15) || ((uintptr_t)out_boxes & 15) || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
     if (workspace_bytes < od_batched_nms_workspace_bytes(batch, num_seg, seg_stride)) return OD_ERR_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
     NmsArgs a;
     a.boxes = (const float4*)boxes;
     a.scores = scores;
@@ -595,27 +730,38 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
     a.num_seg = num_seg;
     a.seg_stride = seg_stride;
     a.n_slots = num_seg * seg_stride;
-    a.n_pad = next_pow2(a.n_slots);
-    a.segments_sorted = segments_sorted;
-    // (double)ovr > thr  <=>  ovr >= thr_up, thr_up = smallest float whose double value exceeds thr
+    a.lazy = (segments_sorted && num_seg <= WSEG) ? 1 : 0;
+    // Threshold rule folded into one float: a pair is suppressed when ovr >= thr_up.
+    //   torchvision's CPU kernel (default):  (double)ovr > thr   <=>  ovr >= smallest float whose double value exceeds thr
+    //   torchvision's CUDA kernel (OD_NMS_THRESHOLD_FLOAT):  ovr > (float)thr  <=>  ovr >= the float after (float)thr
     float f = (float)iou_threshold;
-    if (!((double)f > iou_threshold)) f = __builtin_nextafterf(f, __builtin_inff());
+    if (rule & OD_NMS_THRESHOLD_FLOAT) f = __builtin_nextafterf(f, __builtin_inff());
+    else if (!((double)f > iou_threshold)) f = __builtin_nextafterf(f, __builtin_inff());
     if (iou_threshold != iou_threshold) f = __builtin_nanf("");   // NaN threshold: nothing suppresses
     a.thr_up = f;
     a.can_skip_zero = (iou_threshold >= 0.0) ? 1 : 0;
-    a.mode = mode;
+    a.mode = base_mode;
     a.max_keep = max_keep;
-    a.ws = (float*)workspace;
+    const size_t part = nms_align256((size_t)batch * (size_t)a.n_slots * sizeof(int));
+    char* w = (char*)workspace;
+    a.order = (int*)w;
+    a.kept_out = (int*)(w + part);
+    a.kept_cls = (int*)(w + 2 * part);
+    a.stamps = (unsigned long long*)(w + 3 * part);
     a.keep_idx = (long long*)keep_idx;
     a.out_boxes = (float4*)out_boxes;
     a.out_scores = out_scores;
     a.out_labels = (long long*)out_labels;
     a.out_count = out_count;
     if (max_keep == 0) {
-        OD_HIP(hipMemsetAsync(out_count, 0, sizeof(int) * (size_t)batch, (hipStream_t)stream));
+        OD_HIP(hipMemsetAsync(out_count, 0, sizeof(int) * (size_t)batch, s));
         return OD_OK;
     }
-    OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
+    if (!a.lazy) {
+        OD_LAUNCH_KERNEL(OD_KERNEL_NMS_ORDER, nms_order_kernel, dim3((unsigned)((a.n_slots + OT - 1) / OT), (unsigned)batch),
+                         dim3(OT), 0, s, scores, seg_count, (int)num_seg, (int)seg_stride, a.n_slots, a.order);
+    }
+    OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, s, a);
     return OD_OK;
 }
 
@@ -631,8 +777,8 @@ extern "C" int od_batched_nms(const float* boxes, const float* scores, const int
 }
 
 // ---- od_batched_nms for callers that cannot allocate ---------------------------------------------------------
-// The scratch memory of the NMS kernels (the sorted boxes of every image in SoA form) lives in a device array that
-// is part of the library's code object, so the entry point needs no workspace argument and allocates nothing.
+// The scratch memory of the NMS kernels (the global order of unsorted candidates and the kept lists beyond the LDS
+// cache) lives in a device array that is part of the library's code object, so the entry point needs no workspace argument and allocates nothing.
 // Every GPU holds its own copy of the array at its own address: the address is looked up once per device
 // (hipGetSymbolAddress with that device current) and host code only ever uses that pointer -- the array's name is
 // not a device address on the host side.  All calls on one GPU share the array: calls that overlap in time on one

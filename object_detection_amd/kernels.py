@@ -394,8 +394,8 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
     if nbytes is None:
         nbytes = _ws_bytes[("nms", B, num_seg, int(seg_stride))] = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
     if nbytes == 0 and B > 0:
-        raise _C.OdBoxesError(f"od_batched_nms: {num_seg * seg_stride} boxes per image exceed the limit "
-                              f"of {_C.OD_MAX_NMS_BOXES}")
+        raise _C.OdBoxesError(f"od_batched_nms: {num_seg * seg_stride} boxes per image in {num_seg} segments exceed the "
+                              f"limits of {_C.OD_MAX_NMS_BOXES} boxes and 64 segments")
     ws = _workspace(dev, "nms", nbytes)
     rc = lib.od_batched_nms(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(seg_count.contiguous()), num_seg,
                             int(seg_stride), int(bool(segments_sorted)), B, float(iou_threshold), int(mode), max_keep,

@@ -164,13 +164,16 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
 
 
 def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,
-                        detections_per_img, coder, bbox_xform_clip, ctr_levels=None, nms_mode=_C.NMS_AUTO_GPU,
+                        detections_per_img, coder, bbox_xform_clip, ctr_levels=None,
+                        nms_mode=_C.NMS_AUTO_GPU | _C.NMS_THRESHOLD_FLOAT,
                         return_padded: bool = False, planar_classes: Optional[int] = None,
                         box_scale: Optional[Tensor] = None):
     """Shared tail of RetinaNet / FCOS postprocess_detections: two library calls for the whole batch.
     With ``planar_classes`` (= number of classes) the level tensors are the heads' convolution outputs
     [B, A*K, H, W] instead of the permuted [B, H*W*A, K].  ``box_scale`` [B, 4] multiplies the kept boxes of each image
-    (the rescale of ``transform.postprocess``)."""
+    (the rescale of ``transform.postprocess``).  ``nms_mode``: the default is what torchvision does for tensors on a
+    GPU -- per-class branch above 20000 box coordinates, fp32 comparison with float(nms_thresh) as in its CUDA
+    kernel; ``_C.NMS_AUTO_CPU`` is its behaviour on the CPU (4000, comparison in double)."""
     shared = _shared_levels(anchors)
     if shared is None:
         shared = [torch.stack([a[l] for a in anchors]) for l in range(len(anchors[0]))]

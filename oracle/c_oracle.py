@@ -28,6 +28,8 @@ def lib():
         _lib = ctypes.CDLL(_SO)
         _lib.orc_nms.restype = ctypes.c_int64
         _lib.orc_batched_nms.restype = ctypes.c_int64
+        _lib.orc_nms_rule.restype = ctypes.c_int64
+        _lib.orc_batched_nms_rule.restype = ctypes.c_int64
         _lib.orc_filter_topk.restype = ctypes.c_int64
         _lib.orc_expf.restype = ctypes.c_float
         _lib.orc_expf.argtypes = [ctypes.c_float]
@@ -99,24 +101,27 @@ def match_fcos(gt, anchors, n_first_level, n_last_level, radius=1.5):
     return out
 
 
-def nms(boxes, scores, thr):
+def nms(boxes, scores, thr, float_rule=False):
+    """float_rule: compare the fp32 IoU with float(thr) (torchvision's CUDA kernel) instead of promoting the IoU to
+    double (its CPU kernel)."""
     boxes, bp = _f(np.asarray(boxes).reshape(-1, 4))
     scores, sp = _f(scores)
     n = boxes.shape[0]
     keep = np.empty(max(n, 1), dtype=np.int64)
-    nk = lib().orc_nms(bp, sp, ctypes.c_int64(n), ctypes.c_double(thr), keep.ctypes.data_as(_i64p))
+    nk = lib().orc_nms_rule(bp, sp, ctypes.c_int64(n), ctypes.c_double(thr), ctypes.c_int(int(float_rule)),
+                            keep.ctypes.data_as(_i64p))
     return keep[:nk].copy()
 
 
-def batched_nms(boxes, scores, labels, thr, mode):
+def batched_nms(boxes, scores, labels, thr, mode, float_rule=False):
     """mode: 0 = coordinate trick, 1 = vanilla (per class)."""
     boxes, bp = _f(np.asarray(boxes).reshape(-1, 4))
     scores, sp = _f(scores)
     labels, lp = _i(labels)
     n = boxes.shape[0]
     keep = np.empty(max(n, 1), dtype=np.int64)
-    nk = lib().orc_batched_nms(bp, sp, lp, ctypes.c_int64(n), ctypes.c_double(thr), ctypes.c_int(mode),
-                               keep.ctypes.data_as(_i64p))
+    nk = lib().orc_batched_nms_rule(bp, sp, lp, ctypes.c_int64(n), ctypes.c_double(thr), ctypes.c_int(mode),
+                                    ctypes.c_int(int(float_rule)), keep.ctypes.data_as(_i64p))
     return keep[:nk].copy()
 
 

@@ -184,7 +184,9 @@ void orc_match_fcos(const float* gt, int64_t m, const float* anchors, int64_t n,
     }
 }
 
-/* ---- torchvision/csrc/ops/cpu/nms_kernel.cpp ---------------------------------------------- */
+/* ---- torchvision/csrc/ops/cpu/nms_kernel.cpp (float_rule = 0) and the decision rule of
+ *      torchvision/csrc/ops/cuda/nms_kernel.cu (float_rule = 1: the fp32 IoU is compared with the threshold
+ *      rounded to float; the greedy order and the IoU formula are the same) ------------------ */
 typedef struct { float s; int64_t i; } sidx_t;
 static int cmp_desc_stable(const void* a, const void* b) {
     const sidx_t* x = (const sidx_t*)a; const sidx_t* y = (const sidx_t*)b;
@@ -193,7 +195,7 @@ static int cmp_desc_stable(const void* a, const void* b) {
     return (x->i > y->i) - (x->i < y->i);
 }
 
-int64_t orc_nms(const float* boxes, const float* scores, int64_t n, double thr, int64_t* keep) {
+int64_t orc_nms_rule(const float* boxes, const float* scores, int64_t n, double thr, int float_rule, int64_t* keep) {
     if (n == 0) return 0;
     sidx_t* order = (sidx_t*)malloc(sizeof(sidx_t) * (size_t)n);
     float* areas = (float*)malloc(sizeof(float) * (size_t)n);
@@ -224,16 +226,20 @@ int64_t orc_nms(const float* boxes, const float* scores, int64_t n, double thr, 
             float den = iarea + areas[j];
             den = den - inter;
             float ovr = inter / den;
-            if ((double)ovr > thr) sup[j] = 1;
+            if (float_rule ? (ovr > (float)thr) : ((double)ovr > thr)) sup[j] = 1;
         }
     }
     free(order); free(areas); free(sup);
     return nk;
 }
 
+int64_t orc_nms(const float* boxes, const float* scores, int64_t n, double thr, int64_t* keep) {
+    return orc_nms_rule(boxes, scores, n, thr, 0, keep);
+}
+
 /* mode 0 = _batched_nms_coordinate_trick, 1 = _batched_nms_vanilla */
-int64_t orc_batched_nms(const float* boxes, const float* scores, const int64_t* labels, int64_t n,
-                        double thr, int mode, int64_t* keep) {
+int64_t orc_batched_nms_rule(const float* boxes, const float* scores, const int64_t* labels, int64_t n,
+                             double thr, int mode, int float_rule, int64_t* keep) {
     if (n == 0) return 0;
     if (mode == 0) {
         float mx = boxes[0];
@@ -244,7 +250,7 @@ int64_t orc_batched_nms(const float* boxes, const float* scores, const int64_t* 
             float off = (float)labels[i] * step;
             for (int c = 0; c < 4; ++c) ob[4 * i + c] = boxes[4 * i + c] + off;
         }
-        int64_t nk = orc_nms(ob, scores, n, thr, keep);
+        int64_t nk = orc_nms_rule(ob, scores, n, thr, float_rule, keep);
         free(ob);
         return nk;
     }
@@ -262,7 +268,7 @@ int64_t orc_batched_nms(const float* boxes, const float* scores, const int64_t* 
                 done[i] = 1; ci[c] = i; cs[c] = scores[i];
                 memcpy(cb + 4 * c, boxes + 4 * i, 4 * sizeof(float)); ++c;
             }
-        int64_t nk = orc_nms(cb, cs, c, thr, ck);
+        int64_t nk = orc_nms_rule(cb, cs, c, thr, float_rule, ck);
         for (int64_t k = 0; k < nk; ++k) mask[ci[ck[k]]] = 1;
     }
     sidx_t* order = (sidx_t*)malloc(sizeof(sidx_t) * (size_t)n);
@@ -272,6 +278,11 @@ int64_t orc_batched_nms(const float* boxes, const float* scores, const int64_t* 
     for (int64_t k = 0; k < nk; ++k) keep[k] = order[k].i;
     free(mask); free(done); free(cb); free(cs); free(ci); free(ck); free(order);
     return nk;
+}
+
+int64_t orc_batched_nms(const float* boxes, const float* scores, const int64_t* labels, int64_t n,
+                        double thr, int mode, int64_t* keep) {
+    return orc_batched_nms_rule(boxes, scores, labels, n, thr, mode, 0, keep);
 }
 
 /* ---- torchvision/models/detection/_utils.py: BoxCoder.decode_single (weights 1,1,1,1) ----- */

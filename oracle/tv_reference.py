@@ -102,11 +102,13 @@ def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:
     return clipped.reshape(boxes.shape)
 
 
-def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
+def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, float_rule: bool = False) -> Tensor:
     """torchvision/csrc/ops/cpu/nms_kernel.cpp:nms_kernel_impl, vectorised over the inner loop.
 
     Order = stable descending sort of scores; a later box j is suppressed by a kept box i iff
     fp32 ``inter / (area_i + area_j - inter)`` promoted to double is ``>`` the double threshold.
+    ``float_rule``: the decision of torchvision/csrc/ops/cuda/nms_kernel.cu instead -- the fp32 IoU is compared with
+    the threshold rounded to float (same order, same IoU formula); the two differ when IoU == float(threshold).
     """
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
@@ -135,24 +137,27 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float) -> Tensor:
             h = np.maximum(zero, yy2 - yy1)
             inter = w * h
             ovr = inter / (areas[i] + areas[rest] - inter)
-            suppressed[rest[ovr.astype(np.float64) > thr]] = True
+            if float_rule:
+                suppressed[rest[ovr > np.float32(thr)]] = True
+            else:
+                suppressed[rest[ovr.astype(np.float64) > thr]] = True
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 
-def _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold):
+def _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold, float_rule: bool = False):
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     max_coordinate = boxes.max()
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
     boxes_for_nms = boxes + offsets[:, None]
-    return nms(boxes_for_nms, scores, iou_threshold)
+    return nms(boxes_for_nms, scores, iou_threshold, float_rule)
 
 
-def _batched_nms_vanilla(boxes, scores, idxs, iou_threshold):
+def _batched_nms_vanilla(boxes, scores, idxs, iou_threshold, float_rule: bool = False):
     keep_mask = torch.zeros_like(scores, dtype=torch.bool)
     for class_id in torch.unique(idxs):
         curr_indices = torch.where(idxs == class_id)[0]
-        curr_keep = nms(boxes[curr_indices], scores[curr_indices], iou_threshold)
+        curr_keep = nms(boxes[curr_indices], scores[curr_indices], iou_threshold, float_rule)
         keep_mask[curr_indices[curr_keep]] = True
     keep_indices = torch.where(keep_mask)[0]
     # torchvision calls a non-stable sort here; adopted tie rule: ascending index.
@@ -160,11 +165,15 @@ def _batched_nms_vanilla(boxes, scores, idxs, iou_threshold):
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold, device_rule: str = "cpu"):
-    """torchvision/ops/boxes.py:batched_nms; ``device_rule`` plays ``boxes.device.type``."""
+    """torchvision/ops/boxes.py:batched_nms; ``device_rule`` plays ``boxes.device.type``: it selects the branch
+    (numel > 4000 on "cpu", > 20000 otherwise) and the native kernel whose threshold rule applies ("cpu": double
+    comparison of nms_kernel.cpp; "gpu": float comparison of nms_kernel.cu; "gpu-cpu-threshold": the gpu branch rule
+    with the cpu kernel's comparison)."""
     limit = 4000 if device_rule == "cpu" else 20000
+    float_rule = device_rule == "gpu"
     if boxes.numel() > limit:
-        return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold)
-    return _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold)
+        return _batched_nms_vanilla(boxes, scores, idxs, iou_threshold, float_rule)
+    return _batched_nms_coordinate_trick(boxes, scores, idxs, iou_threshold, float_rule)
 
 
 # --------------------------------------------------------------------------------------------

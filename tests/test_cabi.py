@@ -47,8 +47,10 @@ def test_workspace_sizes_host_only():
     nbytes = lib.od_select_candidates_workspace_bytes(sizes, 2, 3, 4)
     assert nbytes >= 3 * 4040 * 8
     assert lib.od_select_candidates_workspace_bytes(sizes, 99, 3, 4) == 0       # too many levels
-    assert lib.od_batched_nms_workspace_bytes(2, 6, 1000) >= 2 * 7 * 8192 * 4
-    assert lib.od_batched_nms_workspace_bytes(2, 6, 5000) == 0                  # beyond OD_MAX_NMS_BOXES
+    assert lib.od_batched_nms_workspace_bytes(2, 6, 1000) >= 3 * 2 * 6000 * 4
+    assert lib.od_batched_nms_workspace_bytes(2, 6, 5000) >= 3 * 2 * 30000 * 4  # topk_candidates = 5000 on six levels
+    assert lib.od_batched_nms_workspace_bytes(2, 8, 8193) == 0                  # beyond OD_MAX_NMS_BOXES
+    assert lib.od_batched_nms_workspace_bytes(2, 65, 10) == 0                   # too many segments
 
 
 def test_argument_errors_without_gpu():
@@ -60,11 +62,11 @@ def test_argument_errors_without_gpu():
     assert lib.od_match_retinanet(null, 0, 10, null, null, 0, 1, 0.6, 0.5, 1, null, null, 0, null) == -1
     assert lib.od_matcher(null, 0, 5, 0.6, 0.5, 1, null, null, 0, null) == -1
     assert lib.od_batched_nms(null, null, null, null, 1, 10, 0, 1, 0.5, 0, 10, null, null, null, null, null, null, 0, null) == -1
-    assert lib.od_batched_nms(ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16), 1, 9000, 0, 1, 0.5, 0,
+    assert lib.od_batched_nms(ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16), 1, 70000, 0, 1, 0.5, 0,
                               10, null, ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16),
                               ctypes.c_void_p(256), 1 << 30, null) == -2
     # the no-allocation variant rejects sizes beyond its built-in scratch array before anything touches a GPU
-    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 1024, 1, 64, 0.5, 0, 10, null, null, null, null, null,
+    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 8192, 1, 64, 0.5, 0, 10, null, null, null, null, null,
                                       null) == -2
     assert lib.od_batched_nms_noalloc(null, null, null, null, 0, 10, 0, 1, 0.5, 0, 10, null, null, null, null, null,
                                       null) == -1

@@ -143,7 +143,8 @@ def _random_boxes(n, gen, extent=400.0, wh=80.0):
     return torch.cat([xy, xy + sz], dim=1)
 
 
-@pytest.mark.parametrize("n,classes,extent", [(1, 1, 400), (65, 3, 100), (300, 1, 60), (1000, 4, 400), (1500, 5, 150), (6000, 4, 800)])
+@pytest.mark.parametrize("n,classes,extent", [(1, 1, 400), (65, 3, 100), (300, 1, 60), (1000, 4, 400), (1500, 5, 150), (6000, 4, 800),
+                                              (9000, 2, 500)])
 def test_batched_nms(device, n, classes, extent):
     gen = torch.Generator().manual_seed(n + classes)
     boxes = _random_boxes(n, gen, float(extent))
@@ -174,6 +175,107 @@ def test_batched_nms(device, n, classes, extent):
     assert np.array_equal(t_keep.numpy(), o_keep)
 
 
+def _segmented_nms_case(gen, batch, num_seg, seg_stride, classes, extent):
+    """Padded candidate arrays as the selection kernel hands them over: every segment sorted by (score desc, index
+    asc), ragged counts, one empty segment, ties in score inside and across segments."""
+    n = num_seg * seg_stride
+    boxes = torch.stack([_random_boxes(n, gen, float(extent)) for _ in range(batch)])
+    scores = torch.rand((batch, n), generator=gen)
+    scores[:, ::7] = 0.75
+    scores[:, 1::11] = scores[:, :1]
+    scores = scores.view(batch, num_seg, seg_stride).sort(dim=2, descending=True, stable=True)[0].reshape(batch, n)
+    labels = torch.randint(0, classes, (batch, n), generator=gen, dtype=torch.int32)
+    counts = torch.randint(seg_stride // 3, seg_stride + 1, (batch, num_seg), generator=gen, dtype=torch.int32)
+    counts[0, 0] = seg_stride
+    counts[batch - 1, num_seg - 1] = 0
+    return boxes, scores, labels, counts
+
+
+@pytest.mark.parametrize("num_seg,seg_stride,classes,max_keep,extent", [
+    (6, 1000, 4, 500, 1024),          # the benchmark's shape
+    (6, 5000, 91, 300, 1536),         # topk_candidates = 5000: 30 000 candidates per image, lazily merged
+    (6, 5000, 91, 3000, 1536),        # kept list beyond the LDS cache, many classes
+    (8, 700, 1, 2000, 300),           # one class, dense boxes: long kept list, many strips
+    (3, 64, 7, 64, 100),
+    (12, 300, 5, 200, 400),           # more segments than are merged lazily: ranked first
+])
+def test_batched_nms_sorted_segments(device, num_seg, seg_stride, classes, max_keep, extent):
+    """od_batched_nms on pre-sorted padded segments (what postprocess hands over) against the scalar checker run on
+    the concatenation of the valid entries: keep indices, boxes, scores, labels and counts, both branch semantics,
+    both threshold rules."""
+    gen = torch.Generator().manual_seed(num_seg * 131 + seg_stride + classes)
+    B = 2
+    boxes, scores, labels, counts = _segmented_nms_case(gen, B, num_seg, seg_stride, classes, extent)
+    dev = [t.to(device) for t in (boxes, scores, labels, counts)]
+    for mode, omode in ((_C.NMS_TRICK, 0), (_C.NMS_VANILLA, 1)):
+        for flag, frule, thr in ((0, False, 0.3), (_C.NMS_THRESHOLD_FLOAT, True, 0.5)):
+            keep, ob, os_, ol, oc = kernels.batched_nms_padded(dev[0], dev[1], dev[2], dev[3], seg_stride, True, thr,
+                                                               mode | flag, max_keep)
+            for b in range(B):
+                valid = (torch.arange(seg_stride)[None, :] < counts[b][:, None]).reshape(-1)
+                vb, vs, vl = boxes[b][valid], scores[b][valid], labels[b][valid]
+                ref = c_oracle.batched_nms(vb.numpy(), vs.numpy(), vl.numpy(), thr, omode, float_rule=frule)[:max_keep]
+                k = int(oc[b].item())
+                assert k == len(ref), (mode, thr, b, k, len(ref))
+                assert np.array_equal(keep[b, :k].cpu().numpy(), ref), (mode, thr, b)
+                assert torch.equal(ob[b, :k].cpu(), vb[ref]) and torch.equal(os_[b, :k].cpu(), vs[ref])
+                assert torch.equal(ol[b, :k].cpu(), vl[ref].long())
+                assert float(ob[b, k:].abs().sum()) == 0.0 and bool((keep[b, k:] == -1).all())
+
+
+def test_batched_nms_large_unsorted_many_classes(device):
+    """30 000 unsorted candidates with 91 classes in one segment (ranked by the ordering kernel), both branches."""
+    gen = torch.Generator().manual_seed(30091)
+    n, classes = 30000, 91
+    boxes = _random_boxes(n, gen, 1500.0)
+    scores = torch.rand(n, generator=gen)
+    scores[::9] = scores[3]
+    labels = torch.randint(0, classes, (n,), generator=gen)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    for mode, omode in ((_C.NMS_TRICK, 0), (_C.NMS_VANILLA, 1)):
+        ref = c_oracle.batched_nms(boxes.numpy(), scores.numpy(), labels.numpy(), 0.5, omode)
+        for max_keep in (100, n):
+            keep, ob, os_, ol, oc = kernels.batched_nms_padded(boxes[None].to(device), scores[None].to(device),
+                                                               labels[None].to(device), cnt, n, False, 0.5, mode, max_keep)
+            k = int(oc.item())
+            assert k == min(max_keep, len(ref)), (mode, max_keep, k, len(ref))
+            assert np.array_equal(keep[0, :k].cpu().numpy(), ref[:k]), (mode, max_keep)
+            assert torch.equal(ob[0, :k].cpu(), boxes[ref[:k]]) and torch.equal(ol[0, :k].cpu(), labels[ref[:k]])
+
+
+def test_batched_nms_trick_when_classes_are_not_separated(device):
+    """The coordinate trick separates the classes only for non-negative coordinates and labels and a threshold >= 0;
+    otherwise boxes of different classes do interact in torchvision's single nms call, and must here."""
+    gen = torch.Generator().manual_seed(99)
+    n = 700
+    boxes = _random_boxes(n, gen, 300.0, 120.0) - 150.0                 # coordinates in [-150, 270]
+    scores = torch.rand(n, generator=gen)
+    labels = torch.randint(0, 3, (n,), generator=gen)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    cases = [(boxes, labels, 0.3), (boxes + 150.0, labels, -0.5), (boxes + 150.0, labels - 1, 0.3),
+             (boxes + 150.0, labels * 40000, 0.3)]                       # label * (max + 1) beyond 2^23
+    for bx, lab, thr in cases:
+        ref = c_oracle.batched_nms(bx.numpy(), scores.numpy(), lab.numpy(), thr, 0)
+        keep, _, _, ol, oc = kernels.batched_nms_padded(bx[None].to(device), scores[None].to(device),
+                                                        lab[None].to(device), cnt, n, False, thr, _C.NMS_TRICK, n)
+        k = int(oc.item())
+        assert k == len(ref), (thr, k, len(ref))
+        assert np.array_equal(keep[0, :k].cpu().numpy(), ref), thr
+        assert torch.equal(ol[0, :k].cpu(), lab[ref])
+    # per-class branch with labels too far apart to sort (class, rank) as one 32-bit key: candidates stay ungrouped
+    wide = labels * (1 << 29) - 5
+    ref = c_oracle.batched_nms((boxes + 150.0).numpy(), scores.numpy(), wide.numpy(), 0.3, 1)
+    keep, _, _, ol, oc = kernels.batched_nms_padded((boxes + 150.0)[None].to(device), scores[None].to(device),
+                                                    wide[None].to(device), cnt, n, False, 0.3, _C.NMS_VANILLA, n)
+    k = int(oc.item())
+    assert k == len(ref) and np.array_equal(keep[0, :k].cpu().numpy(), ref)
+    assert torch.equal(ol[0, :k].cpu(), wide[ref])
+    # separated classes in the trick branch differ from nothing: the vanilla branch gives the same keep list there
+    ref_v = c_oracle.batched_nms((boxes + 150.0).numpy(), scores.numpy(), labels.numpy(), 0.3, 1)
+    ref_t = c_oracle.batched_nms((boxes + 150.0).numpy(), scores.numpy(), labels.numpy(), 0.3, 0)
+    assert len(ref_v) > 0 and len(ref_t) > 0
+
+
 def test_nms_kat_and_degenerate(device):
     b = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.]])
     s = torch.tensor([.9, .8, .7])
@@ -193,6 +295,17 @@ def test_nms_kat_and_degenerate(device):
     keep, _, _, _, oc = kernels.batched_nms_padded(e[None].to(device), torch.tensor([[.9, .8]], device=device), None,
                                                    cnt2, 2, False, 0.3, _C.NMS_TRICK, 2)
     assert keep[0, :int(oc.item())].cpu().tolist() == c_oracle.nms(e.numpy(), np.float32([.9, .8]), 0.3).tolist() == [0]
+    # the CUDA kernel's rule compares the float IoU with float(0.3): 0.3f > 0.3f is false -> both kept
+    keep, _, _, _, oc = kernels.batched_nms_padded(e[None].to(device), torch.tensor([[.9, .8]], device=device), None,
+                                                   cnt2, 2, False, 0.3, _C.NMS_TRICK | _C.NMS_THRESHOLD_FLOAT, 2)
+    assert keep[0, :int(oc.item())].cpu().tolist() == [0, 1]
+    assert c_oracle.nms(e.numpy(), np.float32([.9, .8]), 0.3, float_rule=True).tolist() == [0, 1]
+    assert tv.nms(e, torch.tensor([.9, .8]), 0.3, float_rule=True).tolist() == [0, 1]
+    assert tv.nms(e, torch.tensor([.9, .8]), 0.3).tolist() == [0]
+    from object_detection_amd import boxes as box_ops
+    sc = torch.tensor([.9, .8], device=device)
+    assert box_ops.nms(e.to(device), sc, 0.3).cpu().tolist() == [0, 1]
+    assert box_ops.nms(e.to(device), sc, 0.3, threshold_rule="cpu").cpu().tolist() == [0]
     # empty image
     cnt0 = torch.tensor([[0]], dtype=torch.int32, device=device)
     _, _, _, _, oc = kernels.batched_nms_padded(e[None].to(device), torch.tensor([[.9, .8]], device=device), None,

@@ -35,7 +35,7 @@ def _outputs(batch, max_keep, device):
             torch.full((batch,), -7, dtype=torch.int32, device=device))
 
 
-def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, seed):
+def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, seed, sorted_segments=1):
     lib = _C.lib()
     boxes, scores, labels, counts = _inputs(batch, num_seg, seg_stride, classes, seed, device)
     stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
@@ -44,12 +44,15 @@ def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, 
     nbytes = lib.od_batched_nms_workspace_bytes(batch, num_seg, seg_stride)
     assert 0 < nbytes <= _C.OD_NMS_NOALLOC_SCRATCH_BYTES
     ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    rc = lib.od_batched_nms(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, 1, batch, thr, mode, max_keep,
+    if not sorted_segments:
+        scores = scores[:, torch.randperm(scores.shape[1])].contiguous()
+    rc = lib.od_batched_nms(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, sorted_segments, batch, thr, mode,
+                            max_keep,
                             *[p(t) for t in want], p(ws), nbytes, stream)
     assert rc == 0
     got = _outputs(batch, max_keep, device)
-    rc = lib.od_batched_nms_noalloc(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, 1, batch, thr, mode,
-                                    max_keep, *[p(t) for t in got], stream)
+    rc = lib.od_batched_nms_noalloc(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, sorted_segments, batch,
+                                    thr, mode, max_keep, *[p(t) for t in got], stream)
     assert rc == 0
     torch.cuda.synchronize(device)
     assert int(want[4].min()) >= 0 and int(want[4].max()) > 0
@@ -59,12 +62,15 @@ def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, 
 
 
 def test_noalloc_nms_matches_workspace_nms_twice(device):
-    # the larger input first: 16 images x 6 segments x 1000 candidates, then 3 images x 4 x 300 in the same scratch
-    first = _run_both(device, 16, 6, 1000, 4, 500, 0.3, _C.NMS_AUTO_GPU, seed=1)
-    second = _run_both(device, 3, 4, 300, 91, 100, 0.5, _C.NMS_VANILLA, seed=2)
-    assert max(first) == 500 and len(second) == 3
+    # The scratch array holds the global order of unsorted candidates and, when more than 1024 boxes may be kept, the
+    # kept lists.  The larger input first: 16 images x 6 x 1000 unsorted candidates keeping up to 3000, then 3 images
+    # x 4 x 300 in the same scratch; then the pipeline's shape (sorted segments, 500 kept), which needs no scratch.
+    first = _run_both(device, 16, 6, 1000, 4, 3000, 0.3, _C.NMS_AUTO_GPU, seed=1, sorted_segments=0)
+    second = _run_both(device, 3, 4, 300, 91, 1100, 0.5, _C.NMS_VANILLA, seed=2, sorted_segments=0)
+    third = _run_both(device, 16, 6, 1000, 4, 500, 0.3, _C.NMS_AUTO_GPU | _C.NMS_THRESHOLD_FLOAT, seed=3)
+    assert max(first) > 1024 and len(second) == 3 and max(third) == 500
     # beyond the built-in scratch array: rejected, nothing launched
     lib = _C.lib()
     null = ctypes.c_void_p(0)
-    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 1024, 1, 64, 0.5, 0, 10, null, null, null, null, null,
+    assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 8192, 1, 64, 0.5, 0, 10, null, null, null, null, null,
                                       null) == -2

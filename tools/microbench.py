@@ -205,11 +205,13 @@ def main():
         kernels.batched_nms_padded(cb, cs, cl, cc, K, True, cfg.nms_thresh, _C.NMS_AUTO_GPU, 500, want_keep_idx=False)
         torch.cuda.synchronize()
         ws = kernels._workspaces[(dev.index, torch.cuda.current_stream(dev).cuda_stream, "nms")]
-        off = cfg.batch * 7 * 8192 * 4
+        off = 3 * ((cfg.batch * cb.shape[1] * 4 + 255) & ~255)       # after the order / kept_out / kept_cls arrays
         st = ws[off:off + cfg.batch * 256].view(torch.int64).view(cfg.batch, 32).cpu()
+        # [0] start, [1] extremes of the image, [2..3] heads; then five stamps per strip: order + class positions,
+        # A (kept list), compaction, B (pairs), C + append; [30] strips done, [31] outputs written
         for b in (0, 5):
             r = st[b]
-            res[f"stamps_us_img{b}"] = [round(float(r[i] - r[0]) / 100.0, 1) for i in list(range(0, 4)) + list(range(4, 20)) + [30, 31]]
+            res[f"stamps_us_img{b}"] = [round(float(r[i] - r[0]) / 100.0, 1) for i in [0, 1] + list(range(4, 32))]
     print(json.dumps(res))
 
 
