@@ -1,13 +1,13 @@
 """Matcher / box coders / loss helpers with the interfaces of
 ``torchvision.models.detection._utils`` (0.16.2), which the reference's models are built from
-(``object_detection/retinanet/retinanet_model.py:4-7``).  Index-producing work runs in HIP kernels;
-the classification-head loss has a fused
-forward/backward kernel pair; the remaining differentiable arithmetic (box losses) stays in PyTorch autograd.
+(``object_detection/retinanet/retinanet_model.py:4-7``).  Matching, decoding and the head losses (forward and
+backward) run in HIP kernels; there is no second implementation in PyTorch ops: inputs the kernels do not take are
+rejected with an error that says what they take.
 """
 from __future__ import annotations
 
 import math
-from typing import List, Optional, Tuple
+from typing import List, Tuple
 
 import torch
 from torch import Tensor
@@ -59,29 +59,18 @@ class BoxCoder:
                             ww * torch.log(gt_w / ex_w), wh * torch.log(gt_h / ex_h)), dim=1)
 
     def decode_single(self, rel_codes: Tensor, boxes: Tensor) -> Tensor:
-        boxes = boxes.to(rel_codes.dtype)
-        needs_grad = torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad)
-        single = rel_codes.dim() == 2 and rel_codes.shape[1] == 4
-        if rel_codes.is_cuda and single and not needs_grad and rel_codes.dtype == torch.float32:
-            codes = rel_codes
-            if tuple(self.weights) != (1.0, 1.0, 1.0, 1.0):
-                codes = rel_codes / rel_codes.new_tensor(self.weights)   # same division torchvision performs
-            return kernels.decode_boxes(codes, boxes, _C.CODER_BOXCODER, self.bbox_xform_clip)
-        widths = boxes[:, 2] - boxes[:, 0]
-        heights = boxes[:, 3] - boxes[:, 1]
-        ctr_x = boxes[:, 0] + 0.5 * widths
-        ctr_y = boxes[:, 1] + 0.5 * heights
-        wx, wy, ww, wh = self.weights
-        dx = rel_codes[:, 0::4] / wx
-        dy = rel_codes[:, 1::4] / wy
-        dw = torch.clamp(rel_codes[:, 2::4] / ww, max=self.bbox_xform_clip)
-        dh = torch.clamp(rel_codes[:, 3::4] / wh, max=self.bbox_xform_clip)
-        pred_ctr_x = dx * widths[:, None] + ctr_x[:, None]
-        pred_ctr_y = dy * heights[:, None] + ctr_y[:, None]
-        half_w = 0.5 * (torch.exp(dw) * widths[:, None])
-        half_h = 0.5 * (torch.exp(dh) * heights[:, None])
-        return torch.stack((pred_ctr_x - half_w, pred_ctr_y - half_h, pred_ctr_x + half_w, pred_ctr_y + half_h),
-                           dim=2).flatten(1)
+        """Boxes decoded from fp32 deltas [n, 4] on the GPU (specified fp32 exp; no autograd graph is built: the
+        differentiable use of this function inside torchvision's ``_box_loss`` is part of the fused loss kernels)."""
+        kernels._require_gpu(rel_codes, "rel_codes")
+        if not (rel_codes.dim() == 2 and rel_codes.shape[1] == 4 and rel_codes.dtype is torch.float32):
+            raise RuntimeError(f"decode_single takes fp32 deltas of shape [n, 4], got {rel_codes.dtype} {tuple(rel_codes.shape)}")
+        if torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad):
+            raise RuntimeError("decode_single builds no autograd graph; gradients of the box loss come from "
+                               "RetinaNetRegressionHead.compute_loss (fused forward and backward kernels)")
+        codes = rel_codes
+        if tuple(self.weights) != (1.0, 1.0, 1.0, 1.0):
+            codes = rel_codes / rel_codes.new_tensor(self.weights)   # same division torchvision performs
+        return kernels.decode_boxes(codes, boxes.to(rel_codes.dtype), _C.CODER_BOXCODER, self.bbox_xform_clip)
 
 
 class BoxLinearCoder:
@@ -102,73 +91,17 @@ class BoxLinearCoder:
         return targets
 
     def decode(self, rel_codes: Tensor, boxes: Tensor) -> Tensor:
-        boxes = boxes.to(dtype=rel_codes.dtype)
-        needs_grad = torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad)
-        if (rel_codes.is_cuda and not needs_grad and self.normalize_by_size and rel_codes.dtype == torch.float32
-                and rel_codes.shape == boxes.shape):
-            return kernels.decode_boxes(rel_codes, boxes, _C.CODER_LINEAR, 0.0).reshape(rel_codes.shape)
-        ctr_x = 0.5 * (boxes[..., 0] + boxes[..., 2])
-        ctr_y = 0.5 * (boxes[..., 1] + boxes[..., 3])
-        if self.normalize_by_size:
-            w = boxes[..., 2] - boxes[..., 0]
-            h = boxes[..., 3] - boxes[..., 1]
-            rel_codes = rel_codes * torch.stack((w, h, w, h), dim=-1)
-        return torch.stack((ctr_x - rel_codes[..., 0], ctr_y - rel_codes[..., 1],
-                            ctr_x + rel_codes[..., 2], ctr_y + rel_codes[..., 3]), dim=-1)
+        kernels._require_gpu(rel_codes, "rel_codes")
+        if not (self.normalize_by_size and rel_codes.dtype is torch.float32 and rel_codes.shape == boxes.shape):
+            raise RuntimeError("BoxLinearCoder.decode takes fp32 codes and boxes of equal shape with normalize_by_size=True")
+        if torch.is_grad_enabled() and (rel_codes.requires_grad or boxes.requires_grad):
+            raise RuntimeError("BoxLinearCoder.decode builds no autograd graph; gradients of the FCOS box loss come "
+                               "from FCOSHead.compute_loss (fused forward and backward kernels)")
+        return kernels.decode_boxes(rel_codes, boxes.to(dtype=rel_codes.dtype), _C.CODER_LINEAR, 0.0).reshape(rel_codes.shape)
 
 
 def _topk_min(input: Tensor, orig_kval: int, axis: int) -> int:
     return min(orig_kval, input.size(axis))
-
-
-# ---- loss helpers (autograd, PyTorch ops) ---------------------------------------------------------
-def sigmoid_focal_loss(inputs: Tensor, targets: Tensor, alpha: float = 0.25, gamma: float = 2,
-                       reduction: str = "none") -> Tensor:
-    p = torch.sigmoid(inputs)
-    ce = torch.nn.functional.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
-    p_t = p * targets + (1 - p) * (1 - targets)
-    loss = ce * ((1 - p_t) ** gamma)
-    if alpha >= 0:
-        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
-    if reduction == "mean":
-        return loss.mean()
-    if reduction == "sum":
-        return loss.sum()
-    return loss
-
-
-def generalized_box_iou_loss(boxes1: Tensor, boxes2: Tensor, reduction: str = "none", eps: float = 1e-7) -> Tensor:
-    x1, y1, x2, y2 = boxes1.unbind(dim=-1)
-    x1g, y1g, x2g, y2g = boxes2.unbind(dim=-1)
-    xk1, yk1 = torch.max(x1, x1g), torch.max(y1, y1g)
-    xk2, yk2 = torch.min(x2, x2g), torch.min(y2, y2g)
-    inter = torch.zeros_like(x1)
-    mask = (yk2 > yk1) & (xk2 > xk1)
-    inter[mask] = (xk2[mask] - xk1[mask]) * (yk2[mask] - yk1[mask])
-    union = (x2 - x1) * (y2 - y1) + (x2g - x1g) * (y2g - y1g) - inter
-    iou = inter / (union + eps)
-    area_c = (torch.max(x2, x2g) - torch.min(x1, x1g)) * (torch.max(y2, y2g) - torch.min(y1, y1g))
-    loss = 1 - (iou - ((area_c - union) / (area_c + eps)))
-    if reduction == "mean":
-        return loss.mean() if loss.numel() > 0 else 0.0 * loss.sum()
-    if reduction == "sum":
-        return loss.sum()
-    return loss
-
-
-def _box_loss(type: str, box_coder: BoxCoder, anchors_per_image: Tensor, matched_gt_boxes_per_image: Tensor,
-              bbox_regression_per_image: Tensor, cnf=None) -> Tensor:
-    torch._assert(type in ["l1", "smooth_l1", "giou"], f"Unsupported loss: {type}")
-    if type == "l1":
-        target = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
-        return torch.nn.functional.l1_loss(bbox_regression_per_image, target, reduction="sum")
-    if type == "smooth_l1":
-        target = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
-        beta = cnf["beta"] if cnf is not None and "beta" in cnf else 1.0
-        return torch.nn.functional.smooth_l1_loss(bbox_regression_per_image, target, reduction="sum", beta=beta)
-    pred = box_coder.decode_single(bbox_regression_per_image, anchors_per_image)
-    eps = torch.finfo(bbox_regression_per_image.dtype).eps
-    return generalized_box_iou_loss(pred, matched_gt_boxes_per_image, reduction="sum", eps=eps)
 
 
 _FUSED_DTYPES = (torch.float32, torch.float16, torch.bfloat16)
@@ -208,14 +141,15 @@ def _matched_rows(matched_idxs: List[Tensor], n: int) -> Tensor:
 
 def retinanet_classification_loss(cls_logits: Tensor, matched_idxs: List[Tensor], labels: List[Tensor],
                                   alpha: float = 0.25, gamma: float = 2.0,
-                                  normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Optional[Tensor]:
-    """Fused path of RetinaNetClassificationHead.compute_loss; None if the inputs do not qualify (not on the GPU,
-    not fp32 / fp16 / bf16, or logits whose inner dimensions are not contiguous) and the caller should use the torch
-    ops.  16-bit logits (a head running under autocast) are read as they are and the loss is evaluated in fp32."""
-    if not (cls_logits.is_cuda and cls_logits.dtype in _FUSED_DTYPES and cls_logits.dim() == 3):
-        return None
+                                  normalization: int = _C.LOSS_NORM_PER_IMAGE) -> Tensor:
+    """RetinaNetClassificationHead.compute_loss for a batch: logits [B, N, C] on the GPU, fp32 / fp16 / bf16.  16-bit
+    logits (a head running under autocast) are read as they are and the loss is evaluated in fp32."""
+    kernels._require_gpu(cls_logits, "cls_logits")
+    if not (cls_logits.dtype in _FUSED_DTYPES and cls_logits.dim() == 3):
+        raise RuntimeError(f"classification loss takes fp32 / fp16 / bf16 logits [B, N, C], got {cls_logits.dtype} "
+                           f"{tuple(cls_logits.shape)}")
     if cls_logits.stride(2) != 1 or cls_logits.stride(1) != cls_logits.shape[2]:
-        return None
+        cls_logits = cls_logits.contiguous()
     B, n = cls_logits.shape[0], cls_logits.shape[1]
     matched = _matched_rows(matched_idxs, n)
     offsets = [0]
@@ -254,22 +188,23 @@ _BOX_LOSS_TYPES = {"l1": _C.BOX_LOSS_L1, "smooth_l1": _C.BOX_LOSS_SMOOTH_L1, "gi
 
 
 def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: Tensor, anchors: List[Tensor],
-                              matched_idxs: List[Tensor], gt_boxes: List[Tensor], cnf=None) -> Optional[Tensor]:
-    """Fused path of RetinaNetRegressionHead.compute_loss; None if the inputs do not qualify (not on the GPU, not
-    fp32 / fp16 / bf16, rows not contiguous, anchors or targets that need a gradient) and the caller should use the torch
-    ops.  Under autocast the regression and the anchors arrive in a 16-bit type: the values are used as they are and
-    the loss is evaluated in fp32."""
+                              matched_idxs: List[Tensor], gt_boxes: List[Tensor], cnf=None) -> Tensor:
+    """RetinaNetRegressionHead.compute_loss for a batch: regression [B, N, 4] on the GPU, fp32 / fp16 / bf16; anchors
+    and targets take no gradient.  Under autocast the regression and the anchors arrive in a 16-bit type: the values
+    are used as they are and the loss is evaluated in fp32."""
     torch._assert(type in _BOX_LOSS_TYPES, f"Unsupported loss: {type}")
-    if not (bbox_regression.is_cuda and bbox_regression.dtype in _FUSED_DTYPES and bbox_regression.dim() == 3):
-        return None
+    kernels._require_gpu(bbox_regression, "bbox_regression")
+    if not (bbox_regression.dtype in _FUSED_DTYPES and bbox_regression.dim() == 3 and bbox_regression.shape[2] == 4):
+        raise RuntimeError(f"regression loss takes fp32 / fp16 / bf16 deltas [B, N, 4], got {bbox_regression.dtype} "
+                           f"{tuple(bbox_regression.shape)}")
     B, n = bbox_regression.shape[0], bbox_regression.shape[1]
-    if (bbox_regression.shape[2] != 4 or bbox_regression.stride(2) != 1 or bbox_regression.stride(1) != 4
+    if (bbox_regression.stride(2) != 1 or bbox_regression.stride(1) != 4
             or bbox_regression.stride(0) % 4 or bbox_regression.data_ptr() % (4 * bbox_regression.element_size())):
-        return None
-    if any(a.requires_grad or a.dtype not in _FUSED_DTYPES or a.shape != (n, 4) for a in anchors):
-        return None
-    if any(g.requires_grad for g in gt_boxes):
-        return None
+        bbox_regression = bbox_regression.contiguous()
+    if any(a.dtype not in _FUSED_DTYPES or a.shape != (n, 4) for a in anchors):
+        raise RuntimeError(f"regression loss takes one [N, 4] floating-point anchor table per image (N = {n})")
+    if any(a.requires_grad for a in anchors) or any(g.requires_grad for g in gt_boxes):
+        raise RuntimeError("regression loss: anchors and target boxes take no gradient")
     first = anchors[0]
     if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
         anchor_table = first.float().contiguous()            # AnchorGenerator hands every image the same tensor
@@ -313,25 +248,28 @@ class _FCOSBoxLoss(torch.autograd.Function):
 
 
 def fcos_head_losses(cls_logits: Tensor, bbox_regression: Tensor, bbox_ctrness: Tensor, anchors: List[Tensor],
-                     matched_idxs: List[Tensor], targets) -> Optional[dict]:
-    """Fused path of FCOSHead.compute_loss: {"classification", "bbox_regression", "bbox_ctrness"}; None if the inputs
-    do not qualify (not on the GPU, element types other than fp32 / fp16 / bf16, rows not contiguous) and the caller
-    should use the torch ops."""
-    ok = (cls_logits.is_cuda and cls_logits.dim() == 3 and bbox_regression.dim() == 3 and bbox_ctrness.dim() == 3
+                     matched_idxs: List[Tensor], targets) -> dict:
+    """FCOSHead.compute_loss for a batch: {"classification", "bbox_regression", "bbox_ctrness"}.  Head outputs on the
+    GPU in one element type (fp32 / fp16 / bf16); anchors and targets take no gradient."""
+    kernels._require_gpu(cls_logits, "cls_logits")
+    ok = (cls_logits.dim() == 3 and bbox_regression.dim() == 3 and bbox_ctrness.dim() == 3
           and cls_logits.dtype in _FUSED_DTYPES and bbox_regression.dtype is cls_logits.dtype
-          and bbox_ctrness.dtype is cls_logits.dtype and bbox_regression.shape[2] == 4 and bbox_ctrness.shape[2] == 1
-          and bbox_regression.stride(2) == 1 and bbox_regression.stride(1) == 4 and bbox_regression.stride(0) % 4 == 0
-          and bbox_regression.data_ptr() % (4 * bbox_regression.element_size()) == 0 and bbox_ctrness.stride(1) == 1
-          and not any(a.requires_grad for a in anchors) and not any(t["boxes"].requires_grad for t in targets))
+          and bbox_ctrness.dtype is cls_logits.dtype and bbox_regression.shape[2] == 4 and bbox_ctrness.shape[2] == 1)
     if not ok:
-        return None
+        raise RuntimeError("FCOS head losses take cls_logits [B, N, C], bbox_regression [B, N, 4] and bbox_ctrness "
+                           "[B, N, 1] of one element type (fp32 / fp16 / bf16)")
+    if any(a.requires_grad for a in anchors) or any(t["boxes"].requires_grad for t in targets):
+        raise RuntimeError("FCOS head losses: anchors and target boxes take no gradient")
+    if not (bbox_regression.stride(2) == 1 and bbox_regression.stride(1) == 4 and bbox_regression.stride(0) % 4 == 0
+            and bbox_regression.data_ptr() % (4 * bbox_regression.element_size()) == 0):
+        bbox_regression = bbox_regression.contiguous()
+    if bbox_ctrness.stride(1) != 1:
+        bbox_ctrness = bbox_ctrness.contiguous()
     n = cls_logits.shape[1]
     if any(a.shape != (n, 4) or a.dtype not in _FUSED_DTYPES for a in anchors):
-        return None
+        raise RuntimeError(f"FCOS head losses take one [N, 4] floating-point anchor table per image (N = {n})")
     cls = retinanet_classification_loss(cls_logits, matched_idxs, [t["labels"] for t in targets],
                                         normalization=_C.LOSS_NORM_BATCH)
-    if cls is None:
-        return None
     first = anchors[0]
     if all(a is first or a.data_ptr() == first.data_ptr() for a in anchors):
         anchor_table = first.float().contiguous()

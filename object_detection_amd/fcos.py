@@ -83,44 +83,8 @@ class FCOSHead(nn.Module):
         cls_logits = head_outputs["cls_logits"]
         bbox_regression = head_outputs["bbox_regression"]
         bbox_ctrness = head_outputs["bbox_ctrness"]
-        if len(targets) > 0:
-            fused = det_utils.fcos_head_losses(cls_logits, bbox_regression, bbox_ctrness, list(anchors),
-                                               list(matched_idxs), targets)
-            if fused is not None:
-                return fused
-        all_cls, all_boxes = [], []
-        for t, m in zip(targets, matched_idxs):
-            if len(t["labels"]) == 0:
-                c = t["labels"].new_zeros((len(m),))
-                bx = t["boxes"].new_zeros((len(m), 4))
-            else:
-                c = t["labels"][m.clip(min=0)]
-                bx = t["boxes"][m.clip(min=0)]
-            c[m < 0] = -1
-            all_cls.append(c)
-            all_boxes.append(bx)
-        all_boxes, all_cls, anchors = torch.stack(all_boxes), torch.stack(all_cls), torch.stack(anchors)
-        fg = all_cls >= 0
-        num_fg = fg.sum().item()
-        cls_target = torch.zeros_like(cls_logits)
-        cls_target[fg, all_cls[fg]] = 1.0
-        loss_cls = det_utils.sigmoid_focal_loss(cls_logits, cls_target, reduction="sum")
-        pred_boxes = self.box_coder.decode(bbox_regression, anchors)
-        loss_reg = det_utils.generalized_box_iou_loss(pred_boxes[fg], all_boxes[fg], reduction="sum")
-        reg_targets = self.box_coder.encode(anchors, all_boxes)
-        if len(reg_targets) == 0:
-            ctr_targets = reg_targets.new_zeros(reg_targets.size()[:-1])
-        else:
-            lr = reg_targets[:, :, [0, 2]]
-            tb = reg_targets[:, :, [1, 3]]
-            ctr_targets = torch.sqrt((lr.min(dim=-1)[0] / lr.max(dim=-1)[0]) * (tb.min(dim=-1)[0] / tb.max(dim=-1)[0]))
-        loss_ctr = nn.functional.binary_cross_entropy_with_logits(bbox_ctrness.squeeze(dim=2)[fg], ctr_targets[fg],
-                                                                  reduction="sum")
-        return {
-            "classification": loss_cls / max(1, num_fg),
-            "bbox_regression": loss_reg / max(1, num_fg),
-            "bbox_ctrness": loss_ctr / max(1, num_fg),
-        }
+        return det_utils.fcos_head_losses(cls_logits, bbox_regression, bbox_ctrness, list(anchors), list(matched_idxs),
+                                          targets)
 
     def forward(self, x: List[Tensor]) -> Dict[str, Tensor]:
         cls_logits = self.classification_head(x)

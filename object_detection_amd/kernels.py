@@ -59,6 +59,18 @@ def _f32c(t: Tensor) -> Tensor:
     return t.contiguous()
 
 
+_pinned_sources: list = []     # pinned host tensors of the uploads below, kept as long as the cached device copies
+
+
+def _upload(host: Tensor, device: torch.device) -> Tensor:
+    """Asynchronous host -> device copy of a small table through pinned memory.  The pinned source is kept with the
+    cached device copy: the copy is only enqueued here, and a copy recorded into a HIP graph reads its source again at
+    every replay (callers that capture graphs fill the cache before the capture starts, see ``graph_step``)."""
+    src = host.pin_memory()
+    _pinned_sources.append(src)
+    return src.to(device, non_blocking=True)
+
+
 def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32) -> Tensor:
     """Small host tuple -> device tensor, cached by value (avoids a host->device copy per call)."""
     key = (device.index, _raw_stream(device), dtype, tuple(int(v) for v in values))     # per stream: the upload is asynchronous
@@ -66,21 +78,27 @@ def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32)
     if t is None:
         if len(_small_cache) > 4096:
             _small_cache.clear()
+            _pinned_sources.clear()
         # through pinned memory and an asynchronous copy: a copy from pageable memory would make the host wait for
         # everything queued on the stream (per step, when the GT counts change every step)
-        t = torch.tensor(list(key[3]), dtype=dtype).pin_memory().to(device, non_blocking=True)
+        t = _upload(torch.tensor(list(key[3]), dtype=dtype), device)
         _small_cache[key] = t
     return t
 
 
 def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
-    """Small host tuple of floats -> fp32 device tensor, cached by value."""
-    key = (device.index, _raw_stream(device), "f32", tuple(float(v) for v in values))
+    """Small host tuple of floats -> fp32 tensor on ``device``, cached by value (per stream on a GPU: the upload is
+    asynchronous; host tensors -- target boxes that were not moved to the GPU yet -- get a plain tensor)."""
+    vals = tuple(float(v) for v in values)
+    if device.type != "cuda":
+        return torch.tensor(vals, dtype=torch.float32, device=device)
+    key = (device.index, _raw_stream(device), "f32", vals)
     t = _small_cache.get(key)
     if t is None:
         if len(_small_cache) > 4096:
             _small_cache.clear()
-        t = torch.tensor(list(key[3]), dtype=torch.float32).pin_memory().to(device, non_blocking=True)
+            _pinned_sources.clear()
+        t = _upload(torch.tensor(list(vals), dtype=torch.float32), device)
         _small_cache[key] = t
     return t
 

@@ -6,7 +6,8 @@ and ``object_detection/predict.py:61``.
 The box pipeline of the model -- anchors, anchor/GT matching in ``compute_loss``, and the whole of
 ``postprocess_detections`` -- runs in the HIP kernels of ``libod_boxes.so``, batched over images
 (no per-image / per-level Python loops, one device->host read per batch for the detection counts).
-Convolutional head layers and the loss arithmetic downstream of matching are ordinary PyTorch.
+The convolutional head layers are ordinary PyTorch modules; the head losses downstream of matching are fused
+forward / backward kernels.
 """
 from __future__ import annotations
 
@@ -20,13 +21,6 @@ from torch import Tensor, nn
 from . import _C, boxes as box_ops, det_utils, kernels
 from .anchor_utils import AnchorGenerator
 from .transform import GeneralizedRCNNTransform
-
-
-def _sum(x: List[Tensor]) -> Tensor:
-    res = x[0]
-    for i in x[1:]:
-        res = res + i
-    return res
 
 
 def _conv_tower(in_channels: int, norm_layer: Optional[Callable[..., nn.Module]]) -> nn.Sequential:
@@ -67,20 +61,8 @@ class RetinaNetClassificationHead(nn.Module):
         self.BETWEEN_THRESHOLDS = det_utils.Matcher.BETWEEN_THRESHOLDS
 
     def compute_loss(self, targets, head_outputs, matched_idxs) -> Tensor:
-        fused = det_utils.retinanet_classification_loss(head_outputs["cls_logits"], list(matched_idxs),
-                                                        [t["labels"] for t in targets])
-        if fused is not None:
-            return fused
-        losses = []
-        for t, logits, m in zip(targets, head_outputs["cls_logits"], matched_idxs):
-            fg = m >= 0
-            num_fg = fg.sum()
-            gt_classes_target = torch.zeros_like(logits)
-            gt_classes_target[fg, t["labels"][m[fg]]] = 1.0
-            valid = m != self.BETWEEN_THRESHOLDS
-            losses.append(det_utils.sigmoid_focal_loss(logits[valid], gt_classes_target[valid], reduction="sum")
-                          / max(1, num_fg))
-        return _sum(losses) / len(targets)
+        return det_utils.retinanet_classification_loss(head_outputs["cls_logits"], list(matched_idxs),
+                                                       [t["labels"] for t in targets])
 
     def forward_maps(self, x: List[Tensor]) -> List[Tensor]:
         """Per-level convolution outputs [B, A*C, H, W], before the permute + reshape of ``forward``."""
@@ -101,19 +83,10 @@ class RetinaNetRegressionHead(nn.Module):
         self._loss_type = "l1"
 
     def compute_loss(self, targets, head_outputs, anchors, matched_idxs) -> Tensor:
-        if len(targets) > 0:
-            fused = det_utils.retinanet_regression_loss(self._loss_type, self.box_coder, head_outputs["bbox_regression"],
-                                                        list(anchors), list(matched_idxs),
-                                                        [t["boxes"] for t in targets])
-            if fused is not None:
-                return fused
-        losses = []
-        for t, reg, a, m in zip(targets, head_outputs["bbox_regression"], anchors, matched_idxs):
-            fg = torch.where(m >= 0)[0]
-            num_fg = fg.numel()
-            losses.append(det_utils._box_loss(self._loss_type, self.box_coder, a[fg, :], t["boxes"][m[fg]],
-                                              reg[fg, :]) / max(1, num_fg))
-        return _sum(losses) / max(1, len(targets))
+        if len(targets) == 0:
+            return head_outputs["bbox_regression"].sum() * 0.0
+        return det_utils.retinanet_regression_loss(self._loss_type, self.box_coder, head_outputs["bbox_regression"],
+                                                   list(anchors), list(matched_idxs), [t["boxes"] for t in targets])
 
     def forward_maps(self, x: List[Tensor]) -> List[Tensor]:
         """Per-level convolution outputs [B, A*4, H, W], before the permute + reshape of ``forward``."""
@@ -163,6 +136,116 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
     return kernels._device_ints(flat, device).view(-1, 2)
 
 
+class _PendingBatch:
+    """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into pinned
+    memory + an event recorded behind it).  ``counts()`` waits for that event once."""
+    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts")
+
+    def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
+        self.boxes, self.scores, self.labels = boxes, scores, labels
+        self.counts_host = torch.empty(counts_dev.shape, dtype=counts_dev.dtype, pin_memory=True)
+        self.counts_host.copy_(counts_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+        self._counts = None
+
+    def counts(self) -> List[int]:
+        if self._counts is None:
+            self.event.synchronize()
+            self._counts = self.counts_host.tolist()
+        return self._counts
+
+
+class Detections(dict):
+    """``{"boxes": [d, 4], "scores": [d], "labels": [d]}`` of one image, as ``postprocess_detections`` returns it.  The
+    number of detections d is only known on the GPU when the call returns; the three tensors are cut out of the padded
+    outputs of the batch at the first access to the dictionary, which waits for the counts of the batch (one
+    event) -- the call itself never makes the host wait for the GPU."""
+
+    def __init__(self, pending: _PendingBatch, index: int):
+        super().__init__()
+        self._pending: Optional[_PendingBatch] = pending
+        self._index = index
+        self._scale: Optional[Tensor] = None
+
+    def defer_box_scale(self, scale: Tensor) -> bool:
+        """Multiply the boxes by ``scale`` [4] when they are cut out (the rescale of ``transform.postprocess``);
+        False if the dictionary is already materialised."""
+        if self._pending is None:
+            return False
+        self._scale = scale if self._scale is None else self._scale * scale
+        return True
+
+    def _materialize(self) -> None:
+        p = self._pending
+        if p is None:
+            return
+        self._pending = None
+        i, c = self._index, p.counts()[self._index]
+        boxes = p.boxes[i, :c]
+        if self._scale is not None:
+            boxes = boxes * self._scale
+        dict.update(self, boxes=boxes, scores=p.scores[i, :c], labels=p.labels[i, :c])
+
+    def __getitem__(self, key):
+        self._materialize()
+        return dict.__getitem__(self, key)
+
+    def __setitem__(self, key, value):
+        self._materialize()
+        dict.__setitem__(self, key, value)
+
+    def __iter__(self):
+        self._materialize()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._materialize()
+        return dict.__len__(self)
+
+    def __contains__(self, key):
+        self._materialize()
+        return dict.__contains__(self, key)
+
+    def __repr__(self):
+        self._materialize()
+        return dict.__repr__(self)
+
+    def __eq__(self, other):
+        self._materialize()
+        return dict.__eq__(self, other)
+
+    __hash__ = None
+
+    def keys(self):
+        self._materialize()
+        return dict.keys(self)
+
+    def values(self):
+        self._materialize()
+        return dict.values(self)
+
+    def items(self):
+        self._materialize()
+        return dict.items(self)
+
+    def get(self, key, default=None):
+        self._materialize()
+        return dict.get(self, key, default)
+
+    def pop(self, *args):
+        self._materialize()
+        return dict.pop(self, *args)
+
+    def update(self, *args, **kwargs):
+        self._materialize()
+        dict.update(self, *args, **kwargs)
+
+    def copy(self):
+        self._materialize()
+        return dict.copy(self)
+
+
 def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,
                         detections_per_img, coder, bbox_xform_clip, ctr_levels=None,
                         nms_mode=_C.NMS_AUTO_GPU | _C.NMS_THRESHOLD_FLOAT,
@@ -173,7 +256,9 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
     [B, A*K, H, W] instead of the permuted [B, H*W*A, K].  ``box_scale`` [B, 4] multiplies the kept boxes of each image
     (the rescale of ``transform.postprocess``).  ``nms_mode``: the default is what torchvision does for tensors on a
     GPU -- per-class branch above 20000 box coordinates, fp32 comparison with float(nms_thresh) as in its CUDA
-    kernel; ``_C.NMS_AUTO_CPU`` is its behaviour on the CPU (4000, comparison in double)."""
+    kernel; ``_C.NMS_AUTO_CPU`` is its behaviour on the CPU (4000, comparison in double).
+    Returns the list of per-image ``Detections`` (cut to size on first access, no host wait here), or with
+    ``return_padded`` the padded tensors (boxes [B, D, 4], scores [B, D], labels [B, D], counts [B])."""
     shared = _shared_levels(anchors)
     if shared is None:
         shared = [torch.stack([a[l] for a in anchors]) for l in range(len(anchors[0]))]
@@ -193,8 +278,8 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
         ob = ob * box_scale[:, None, :]
     if return_padded:
         return ob, os_, ol, oc
-    counts = oc.tolist()   # the one device->host read: detections are variable-length tensors
-    return [{"boxes": ob[i, :c], "scores": os_[i, :c], "labels": ol[i, :c]} for i, c in enumerate(counts)]
+    pending = _PendingBatch(ob, os_, ol, oc)
+    return [Detections(pending, i) for i in range(ob.shape[0])]
 
 
 class RetinaNet(nn.Module):

@@ -526,6 +526,98 @@ def retinanet_postprocess(head_outputs: Dict[str, List[Tensor]], anchors: List[L
 
 
 # --------------------------------------------------------------------------------------------
+# torchvision/models/detection/transform.py (the reference configures it through
+# get_model(min_size=size, max_size=size), object_detection/train.py:142-144)
+# --------------------------------------------------------------------------------------------
+def resize_boxes(boxes: Tensor, original_size: Sequence[int], new_size: Sequence[int]) -> Tensor:
+    ratios = [torch.tensor(s, dtype=torch.float32, device=boxes.device)
+              / torch.tensor(s_orig, dtype=torch.float32, device=boxes.device)
+              for s, s_orig in zip(new_size, original_size)]
+    ratio_height, ratio_width = ratios
+    xmin, ymin, xmax, ymax = boxes.unbind(1)
+    xmin = xmin * ratio_width
+    xmax = xmax * ratio_width
+    ymin = ymin * ratio_height
+    ymax = ymax * ratio_height
+    return torch.stack((xmin, ymin, xmax, ymax), dim=1)
+
+
+def _resize_image(image: Tensor, self_min_size: int, self_max_size: int, fixed_size=None) -> Tensor:
+    im_shape = torch.tensor(image.shape[-2:])
+    size = None
+    scale_factor = None
+    recompute_scale_factor = None
+    if fixed_size is not None:
+        size = [fixed_size[1], fixed_size[0]]
+    else:
+        min_size = torch.min(im_shape).to(dtype=torch.float32)
+        max_size = torch.max(im_shape).to(dtype=torch.float32)
+        scale = torch.min(self_min_size / min_size, self_max_size / max_size)
+        scale_factor = scale.item()
+        recompute_scale_factor = True
+    return torch.nn.functional.interpolate(image[None], size=size, scale_factor=scale_factor, mode="bilinear",
+                                           recompute_scale_factor=recompute_scale_factor, align_corners=False)[0]
+
+
+class GeneralizedRCNNTransform:
+    """``GeneralizedRCNNTransform.forward`` in eval or train mode with one ``min_size`` (what the reference passes):
+    normalize -> bilinear resize (``recompute_scale_factor=True``) with ``resize_boxes`` of the targets -> zero-padded
+    batch whose sides are multiples of ``size_divisible``; ``postprocess`` rescales detections."""
+
+    def __init__(self, min_size: int, max_size: int, image_mean, image_std, size_divisible: int = 32, fixed_size=None):
+        self.min_size, self.max_size = min_size, max_size
+        self.image_mean, self.image_std = image_mean, image_std
+        self.size_divisible, self.fixed_size = size_divisible, fixed_size
+
+    def normalize(self, image: Tensor) -> Tensor:
+        dtype, device = image.dtype, image.device
+        mean = torch.as_tensor(self.image_mean, dtype=dtype, device=device)
+        std = torch.as_tensor(self.image_std, dtype=dtype, device=device)
+        return (image - mean[:, None, None]) / std[:, None, None]
+
+    def resize(self, image: Tensor, target=None):
+        h, w = image.shape[-2:]
+        image = _resize_image(image, float(self.min_size), float(self.max_size), self.fixed_size)
+        if target is None:
+            return image, target
+        target = dict(target)
+        target["boxes"] = resize_boxes(target["boxes"], (h, w), image.shape[-2:])
+        return image, target
+
+    def batch_images(self, images: List[Tensor]) -> Tensor:
+        max_size = [max(s) for s in zip(*[list(img.shape) for img in images])]
+        stride = float(self.size_divisible)
+        max_size[1] = int(math.ceil(float(max_size[1]) / stride) * stride)
+        max_size[2] = int(math.ceil(float(max_size[2]) / stride) * stride)
+        batched = images[0].new_full([len(images)] + max_size, 0)
+        for i in range(batched.shape[0]):
+            img = images[i]
+            batched[i, : img.shape[0], : img.shape[1], : img.shape[2]].copy_(img)
+        return batched
+
+    def forward(self, images: List[Tensor], targets=None):
+        images = [img for img in images]
+        targets = None if targets is None else [dict(t) for t in targets]
+        for i in range(len(images)):
+            image = self.normalize(images[i])
+            image, t = self.resize(image, None if targets is None else targets[i])
+            images[i] = image
+            if targets is not None:
+                targets[i] = t
+        image_sizes = [(int(img.shape[-2]), int(img.shape[-1])) for img in images]
+        return self.batch_images(images), image_sizes, targets
+
+    @staticmethod
+    def postprocess(result, image_shapes, original_image_sizes):
+        out = []
+        for pred, im_s, o_im_s in zip(result, image_shapes, original_image_sizes):
+            pred = dict(pred)
+            pred["boxes"] = resize_boxes(pred["boxes"], im_s, o_im_s)
+            out.append(pred)
+        return out
+
+
+# --------------------------------------------------------------------------------------------
 # torchvision/models/detection/fcos.py
 # --------------------------------------------------------------------------------------------
 def fcos_match(targets_boxes: List[Tensor], anchors: List[Tensor], num_anchors_per_level: List[int],

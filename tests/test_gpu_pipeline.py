@@ -482,6 +482,96 @@ def test_concurrent_streams_do_not_share_scratch(device):
             assert torch.equal(a, b), f"stream {i}"
 
 
+def test_graph_capture_replays_step(device):
+    """A whole step (candidate selection + NMS on the capture stream, anchor matching forked onto a second stream) is
+    recorded into a HIP graph once and replayed: the replay's outputs equal those of the same calls issued one by one,
+    also after new values were copied into the captured input tensors."""
+    from object_detection_amd import graph_step
+    base = synthetic.CFG1
+    model = _model(base, device)
+    anchors_l = _anchors(model, base, device)
+    anchors = torch.cat(anchors_l)
+    sizes = synthetic.level_sizes(base)
+    shapes = [base.image_size] * base.batch
+    cfgs = [dataclasses.replace(base, cfg_id=60 + i, num_gt=50) for i in range(2)]
+    heads = [{k: v.to(device) for k, v in synthetic.make_head_outputs(c).items()} for c in cfgs]
+    gts = [[t["boxes"].to(device) for t in synthetic.make_targets(c)] for c in cfgs]
+    static_head = {k: v.clone() for k, v in heads[0].items()}
+    static_gt = [g.clone() for g in gts[0]]
+    split = {k: list(v.split(sizes, dim=1)) for k, v in static_head.items()}
+    side = torch.cuda.Stream(device)
+
+    def step():
+        main = torch.cuda.current_stream(device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            matched = kernels.match_retinanet(anchors, static_gt, 0.6, 0.5, True)
+        out = postprocess_batched(split["cls_logits"], split["bbox_regression"], [anchors_l] * base.batch, shapes,
+                                  model.score_thresh, model.topk_candidates, model.nms_thresh, model.detections_per_img,
+                                  _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip, return_padded=True)
+        main.wait_stream(side)
+        return out + (matched,)
+
+    def eager(head, gt):
+        sp = {k: list(v.split(sizes, dim=1)) for k, v in head.items()}
+        out = postprocess_batched(sp["cls_logits"], sp["bbox_regression"], [anchors_l] * base.batch, shapes,
+                                  model.score_thresh, model.topk_candidates, model.nms_thresh, model.detections_per_img,
+                                  _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip, return_padded=True)
+        return out + (kernels.match_retinanet(anchors, gt, 0.6, 0.5, True),)
+
+    want = [[t.clone() for t in eager(heads[i], gts[i])] for i in range(2)]
+    torch.cuda.synchronize()
+    captured = graph_step.capture(step, device, side_streams=[side])
+    for rep in range(2):
+        for i in (0, 1, 0):
+            for k in static_head:
+                static_head[k].copy_(heads[i][k])
+            for dst, src in zip(static_gt, gts[i]):
+                dst.copy_(src)
+            got = captured.replay()
+            torch.cuda.synchronize()
+            for a, b, name in zip(got, want[i], ("boxes", "scores", "labels", "counts", "matched")):
+                assert torch.equal(a, b), (rep, i, name)
+    assert int(want[0][3].min()) > 0 and not torch.equal(want[0][4], want[1][4])
+
+
+def test_detections_are_cut_to_size_on_first_access(device):
+    """postprocess_detections returns dictionaries whose tensors are cut out of the padded batch outputs when they
+    are first looked at (the call itself does not wait for the GPU); they behave like plain dictionaries."""
+    from object_detection_amd.retinanet import Detections
+    cfg = synthetic.CFG1
+    model = _model(cfg, device)
+    anchors = _anchors(model, cfg, device)
+    sizes = synthetic.level_sizes(cfg)
+    head = synthetic.make_head_outputs(cfg)
+    shapes = [(512, 512), (500, 470)]
+    split = {k: [t.to(device) for t in v.split(sizes, dim=1)] for k, v in head.items()}
+    dets = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    ob, os_, ol, oc = postprocess_batched(split["cls_logits"], split["bbox_regression"], [anchors] * cfg.batch, shapes,
+                                          model.score_thresh, model.topk_candidates, model.nms_thresh,
+                                          model.detections_per_img, _C.CODER_BOXCODER, model.box_coder.bbox_xform_clip,
+                                          return_padded=True)
+    assert all(isinstance(d, Detections) and isinstance(d, dict) and d._pending is not None for d in dets)
+    counts = oc.tolist()
+    assert set(dets[0].keys()) == {"boxes", "scores", "labels"} and dets[0]._pending is None
+    plain = dict(dets[1])                                    # the generic mapping protocol materialises as well
+    assert sorted(plain) == ["boxes", "labels", "scores"] and len(dets[1]) == 3 and "boxes" in dets[1]
+    for i, d in enumerate(dets):
+        assert torch.equal(d["boxes"], ob[i, :counts[i]]) and torch.equal(d["scores"], os_[i, :counts[i]])
+        assert torch.equal(d["labels"], ol[i, :counts[i]]) and d["labels"].dtype is torch.int64
+    # the rescale of transform.postprocess is applied when the boxes are cut out
+    again = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    model.transform.eval()
+    scaled = model.transform.postprocess(again, shapes, [(1024, 1024), (250, 940)])
+    assert scaled[0]._pending is not None
+    ref = tv.GeneralizedRCNNTransform.postprocess([{"boxes": ob[i, :counts[i]].cpu()} for i in range(cfg.batch)], shapes,
+                                                  [(1024, 1024), (250, 940)])
+    for d, r in zip(scaled, ref):
+        assert torch.equal(d["boxes"].cpu(), r["boxes"])
+    scaled[0]["boxes"] = scaled[0]["boxes"] + 1.0            # item assignment works on the materialised dictionary
+    assert torch.equal(scaled[0]["boxes"].cpu(), ref[0]["boxes"] + 1.0)
+
+
 def test_fused_classification_loss_forward_and_backward(device):
     """Fused focal-loss kernels against the torch restatement of RetinaNetClassificationHead.compute_loss (fp32 on the
     CPU): loss within 1e-5 relative, gradient within 1e-5 of its largest entry plus 1e-4 relative per element."""

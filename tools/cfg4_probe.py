@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from object_detection_amd import _C, kernels, synthetic  # noqa: E402
 from object_detection_amd.retinanet import _image_hw_tensor  # noqa: E402
-from oracle import tv_reference as tv  # noqa: E402
+from object_detection_amd.anchor_utils import AnchorGenerator  # noqa: E402
 from tools.microbench import timed  # noqa: E402
 
 
@@ -20,7 +20,7 @@ def main():
     dev = torch.device("cuda:0")
     cfg = dataclasses.replace(synthetic.CFG4, batch=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     sizes = synthetic.level_sizes(cfg)
-    ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
+    ag = AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
     grids = [(g, g) for g in cfg.grids]
     strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
     anchors = kernels.anchor_generate(grids, strides, ag.cell_anchors, dev)

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from object_detection_amd import _C, kernels, synthetic  # noqa: E402
 from object_detection_amd.retinanet import _image_hw_tensor  # noqa: E402
-from oracle import tv_reference as tv  # noqa: E402
+from object_detection_amd.anchor_utils import AnchorGenerator  # noqa: E402
 from tools.microbench import timed  # noqa: E402
 
 
@@ -30,7 +30,7 @@ def main():
     # ---- FCOS: centre-sampling matching and postprocess ---------------------------------------------------------
     cfg = synthetic.CFG3
     sizes = synthetic.level_sizes(cfg)
-    ag = tv.AnchorGenerator(((8,), (16,), (32,), (64,), (128,)), ((1.0,),) * 5)
+    ag = AnchorGenerator(((8,), (16,), (32,), (64,), (128,)), ((1.0,),) * 5)
     grids = [(g, g) for g in cfg.grids]
     strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
     anchors = kernels.anchor_generate(grids, strides, ag.cell_anchors, dev)
@@ -57,7 +57,7 @@ def main():
 
     # ---- dense RetinaNet matching: 2000 GT per image ------------------------------------------------------------------
     cfg5 = synthetic.CFG5
-    ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg5.grids)), ((0.5, 1.0, 2.0),) * len(cfg5.grids))
+    ag = AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg5.grids)), ((0.5, 1.0, 2.0),) * len(cfg5.grids))
     grids = [(g, g) for g in cfg5.grids]
     strides = [(cfg5.image_size[0] // g, cfg5.image_size[1] // g) for g in cfg5.grids]
     anchors = kernels.anchor_generate(grids, strides, ag.cell_anchors, dev)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from object_detection_amd import _C, kernels, synthetic  # noqa: E402
 from object_detection_amd.retinanet import _image_hw_tensor  # noqa: E402
-from oracle import tv_reference as tv  # noqa: E402
+from object_detection_amd.anchor_utils import AnchorGenerator  # noqa: E402
 
 
 REPS, WARM = 20, 3
@@ -56,7 +56,7 @@ def main():
     dev = torch.device("cuda:0")
     cfg = dataclasses.replace(synthetic.CFG2, batch=args.batch, num_gt=args.gt, grids=synthetic.CFG2.grids[:args.levels])
     sizes = synthetic.level_sizes(cfg)
-    ag = tv.AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
+    ag = AnchorGenerator(synthetic.retinanet_anchor_sizes(len(cfg.grids)), ((0.5, 1.0, 2.0),) * len(cfg.grids))
     grids = [(g, g) for g in cfg.grids]
     strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
     anchors = kernels.anchor_generate(grids, strides, ag.cell_anchors, dev)
@@ -150,7 +150,6 @@ def main():
         # training side of the model: compute_loss forward + backward for the batch, fused kernels against the same
         # steps as torch ops on the GPU (per-image loop, as torchvision writes it)
         import time
-        from object_detection_amd import det_utils
         from object_detection_amd.retinanet_model import get_model
         L = len(cfg.grids)
         model = get_model(cfg.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
@@ -163,6 +162,26 @@ def main():
             losses = model.compute_loss(targets, head, apl)
             (losses["classification"] + losses["bbox_regression"]).backward()
 
+        def focal(x, t):                          # sigmoid_focal_loss, alpha 0.25, gamma 2, summed
+            p = torch.sigmoid(x)
+            ce = torch.nn.functional.binary_cross_entropy_with_logits(x, t, reduction="none")
+            p_t = p * t + (1 - p) * (1 - t)
+            return ((0.25 * t + 0.75 * (1 - t)) * ce * (1 - p_t) ** 2).sum()
+
+        def giou_sum(reg, anc, gt):               # decode_single + generalized_box_iou_loss, summed
+            w, h = anc[:, 2] - anc[:, 0], anc[:, 3] - anc[:, 1]
+            cx, cy = anc[:, 0] + 0.5 * w, anc[:, 1] + 0.5 * h
+            pcx, pcy = reg[:, 0] * w + cx, reg[:, 1] * h + cy
+            pw = torch.exp(reg[:, 2].clamp(max=4.135166556742356)) * w
+            ph = torch.exp(reg[:, 3].clamp(max=4.135166556742356)) * h
+            x1, y1, x2, y2 = pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph
+            xk1, yk1 = torch.max(x1, gt[:, 0]), torch.max(y1, gt[:, 1])
+            xk2, yk2 = torch.min(x2, gt[:, 2]), torch.min(y2, gt[:, 3])
+            inter = ((xk2 - xk1).clamp(min=0) * (yk2 - yk1).clamp(min=0))
+            union = (x2 - x1) * (y2 - y1) + (gt[:, 2] - gt[:, 0]) * (gt[:, 3] - gt[:, 1]) - inter
+            area_c = (torch.max(x2, gt[:, 2]) - torch.min(x1, gt[:, 0])) * (torch.max(y2, gt[:, 3]) - torch.min(y1, gt[:, 1]))
+            return (1 - inter / (union + 1e-7) + (area_c - union) / (area_c + 1e-7)).sum()
+
         def torch_step():
             matched = model.match_anchors(targets, apl)
             cls_losses, reg_losses = [], []
@@ -171,10 +190,9 @@ def main():
                 tgt = torch.zeros_like(logits)
                 tgt[fg, t["labels"][m[fg]]] = 1.0
                 valid = m != -2
-                cls_losses.append(det_utils.sigmoid_focal_loss(logits[valid], tgt[valid], reduction="sum") / max(1, int(fg.sum())))
+                cls_losses.append(focal(logits[valid], tgt[valid]) / max(1, int(fg.sum())))
                 fi = torch.where(fg)[0]
-                reg_losses.append(det_utils._box_loss("giou", model.head.regression_head.box_coder, anchors[fi],
-                                                      t["boxes"][m[fi]], reg[fi]) / max(1, fi.numel()))
+                reg_losses.append(giou_sum(reg[fi], anchors[fi], t["boxes"][m[fi]]) / max(1, fi.numel()))
             (sum(cls_losses) / cfg.batch + sum(reg_losses) / cfg.batch).backward()
 
         for name, fn, reps in (("fused", fused_step, 20), ("torch_ops_after_fused_matching", torch_step, 3)):
