@@ -37,9 +37,10 @@ from object_detection_amd.retinanet_model import get_model  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 NUM_CUS = 256            # compute units of one MI355X
-# HBM bytes per launch from the rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE; collected by tools/pmc_bench.sh in
-# separate profiler runs of this same script and committed): PMC counters cannot be read from inside the process.
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+# HBM bytes and VALU instructions per launch from the rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU;
+# collected by tools/pmc_r02.sh in separate profiler runs of this same script and committed): PMC counters cannot be
+# read from inside the process.
+PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
 
 
 def pmc_traffic(kernel: str):
@@ -155,6 +156,17 @@ def launch_ranks(n: int) -> int:
     return status
 
 
+def pmc_valu(kernel: str):
+    """VALU instructions per launch (SQ_INSTS_VALU summed over the waves) from the committed counter pass, or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_valu_match.json")) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    entry = table.get(kernel + "_kernel")
+    return None if entry is None else entry.get("valu_insts_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,11 +175,14 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=48,
                     help="images in the CPU-baseline sample (0 = skip); 48 = three batches, 10-15 s of CPU work")
     ap.add_argument("--streams", type=int, default=3, choices=(1, 2, 3, 4),
-                    help="2: the inference half and the training half of a step run on HIP streams of their own; "
-                         "3: in addition the inference halves of consecutive steps alternate between two streams")
-    ap.add_argument("--rotate", type=int, default=3,
-                    help="resident input batches used in rotation by consecutive steps (3 x 403 MB of head outputs: "
-                         "more than twice the 256 MiB last-level cache)")
+                    help="eager mode: 2: the inference half and the training half of a step run on HIP streams of their "
+                         "own; 3: in addition the inference halves of consecutive steps alternate between two streams")
+    ap.add_argument("--rotate", type=int, default=4,
+                    help="resident input batches used in rotation by consecutive steps (4 x 403 MB of head outputs: "
+                         "several times the 256 MiB last-level cache); rounded up to an even number")
+    ap.add_argument("--graph", action="store_true",
+                    help="timed region: replay the step's recorded HIP graph instead of launching every kernel from the "
+                         "host (measured slower on this runtime; without the flag the replay rate is a secondary figure)")
     ap.add_argument("--lean", action="store_true",
                     help="only warm-up, kernel probe and the timed region (for profiling: the kernel statistics of the "
                          "run are then those of the timed region); the secondary figures are reported as null")
@@ -188,7 +203,7 @@ def main():
     rehearsal = bool(os.environ.get("OD_BENCH_REHEARSAL"))
     if rehearsal:
         import faulthandler
-        faulthandler.dump_traceback_later(150, exit=True)      # a hang ends with the stack of every thread
+        faulthandler.dump_traceback_later(170, exit=True)      # a hang ends with the stack of every thread
         local_rank = 0
     if world > 1:
         import torch.distributed as dist
@@ -199,6 +214,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    use_graph = args.graph
 
     cfg = synthetic.CFG2
     L = len(cfg.grids)
@@ -214,9 +230,10 @@ def main():
     anchors_flat = torch.cat(anchors_l) if len(anchors_l) > 1 else anchors_l[0]
     assert anchors_flat.shape[0] == cfg.num_anchors
     # Several resident batches, used in rotation: a step never finds its logits, regression values or GT boxes in the
-    # 256 MiB last-level cache because the previous step left them there (one batch is 403 MB of head outputs).
+    # 256 MiB last-level cache because an earlier step left them there (one batch is 403 MB of head outputs).
+    n_rot = max(2, args.rotate + (args.rotate & 1))
     batches = []
-    for r in range(max(1, args.rotate)):
+    for r in range(n_rot):
         head, targets_r = build_inputs(dataclasses.replace(cfg, cfg_id=cfg.cfg_id + 10 * r), rank, dev)
         batches.append(({k: list(v.split(sizes, dim=1)) for k, v in head.items()}, targets_r))
     split, targets = batches[0]
@@ -224,61 +241,93 @@ def main():
     anchors_per_image = [anchors_flat] * cfg.batch
     split_anchors = [anchors_l] * cfg.batch
 
+    from object_detection_amd import graph_step
     from object_detection_amd.retinanet import postprocess_batched
 
-    # Host copies of the detection counts (what postprocess_detections needs to slice its padded outputs into the
-    # per-image lists): one pinned row per step, filled by an asynchronous copy and read after the last step,
-    # inside the timed region.  A step therefore never stalls the GPU on a host round trip.
-    counts_host = torch.empty((max(args.steps, args.warmup, 3), cfg.batch), dtype=torch.int32).pin_memory()
-    count_rows = list(counts_host.unbind(0))              # the row views, made once
+    def post_padded(r):
+        sp = batches[r][0]
+        return postprocess_batched(sp["cls_logits"], sp["bbox_regression"], split_anchors, shapes, model.score_thresh,
+                                   model.topk_candidates, model.nms_thresh, model.detections_per_img, _C.CODER_BOXCODER,
+                                   model.box_coder.bbox_xform_clip, return_padded=True)
 
+    # ---- eager form of a step: every kernel is launched from the host ------------------------------------------
     # The two halves of a step are independent, so each gets a HIP stream of its own: the narrow kernels of the
     # inference half (top-k: 96 workgroups, NMS: one workgroup per image) then run beside the chip-wide matching
     # kernels instead of leaving most CUs idle.  Scratch buffers are per stream (kernels._workspace).
     # With a third stream the inference halves of consecutive steps alternate between two streams, so that the
     # NMS of one step also runs beside the score filter of the next.
+    counts_host = torch.empty((max(args.steps, args.warmup, 3), cfg.batch), dtype=torch.int32).pin_memory()
+    count_rows = list(counts_host.unbind(0))              # the row views, made once
     two = args.streams >= 2
     n_post = {1: 1, 2: 1, 3: 2, 4: 2}[args.streams]
     s_posts = [torch.cuda.Stream(dev) for _ in range(n_post)] if two else [torch.cuda.current_stream(dev)]
     s_matches = [torch.cuda.Stream(dev) for _ in range(args.streams - n_post)] if two else [torch.cuda.current_stream(dev)]
+    default_stream = torch.cuda.current_stream(dev)
     for st in s_posts + s_matches:
-        st.wait_stream(torch.cuda.current_stream(dev))
+        st.wait_stream(default_stream)
 
-    def run_post(i, sync_host):
-        split = batches[i % len(batches)][0]
-        ob, os_, ol, oc = postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
-                                              model.score_thresh, model.topk_candidates, model.nms_thresh,
-                                              model.detections_per_img, _C.CODER_BOXCODER,
-                                              model.box_coder.bbox_xform_clip, return_padded=True)
+    def eager_step(i=0, mode="padded", single_stream=False):
+        """mode "padded": padded outputs, counts copied to pinned memory asynchronously; "api": the model's own
+        postprocess_detections (per-image dictionaries, cut to size when first looked at); "api-blocking": the same,
+        and the host looks at them right away."""
+        r = i % n_rot
+        # set_stream, not the `with torch.cuda.stream(...)` context manager: the manager's enter / exit cost the
+        # host several microseconds each, twice per step
+        torch.cuda.set_stream(default_stream if single_stream or not two else s_posts[i % len(s_posts)])
+        if mode == "padded":
+            ob, os_, ol, oc = post_padded(r)
+            if world > 1:
+                sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
+            count_rows[i % len(count_rows)].copy_(oc, non_blocking=True)
+            out = oc
+        else:
+            out = model.postprocess_detections(batches[r][0], split_anchors, shapes)
+            if mode == "api-blocking":
+                out[0]["boxes"]
+        torch.cuda.set_stream(default_stream if single_stream or not two else s_matches[i % len(s_matches)])
+        matched = model.match_anchors(batches[r][1], anchors_per_image)
+        return matched, out
+
+    # ---- recorded form: one HIP graph per resident batch; inside it the matching half is forked onto a stream of its
+    # own.  Graphs of consecutive steps are replayed on two launch streams in turn, so that the narrow tail of one
+    # step (top-k, NMS) runs beside the chip-wide kernels of the next.  Every graph was recorded on streams of its own
+    # and therefore owns its scratch buffers; a graph is always replayed on the same launch stream.
+    launch_streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    graphs, accumulators = [], []
+
+    def record_graphs():
+        for r in range(n_rot):
+            side = torch.cuda.Stream(dev)
+            acc = torch.zeros((cfg.batch,), dtype=torch.int32, device=dev)     # detections of all replays, per image
+
+            def recorded(r=r, side=side, acc=acc):
+                main = torch.cuda.current_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    matched = model.match_anchors(batches[r][1], anchors_per_image)
+                ob, os_, ol, oc = post_padded(r)
+                acc.add_(oc)
+                main.wait_stream(side)
+                return ob, os_, ol, oc, matched
+
+            graphs.append(graph_step.capture(recorded, dev, warmup=2, side_streams=[side]))
+            accumulators.append(acc)
+        torch.cuda.synchronize(dev)
+        for acc in accumulators:
+            acc.zero_()
+
+    if use_graph:
+        record_graphs()
+
+    def graph_step_run(i):
+        r = i % n_rot
+        torch.cuda.set_stream(launch_streams[r & 1])
+        ob, os_, ol, oc, matched = graphs[r].replay()
         if world > 1:
             sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
-        if sync_host:
-            oc.tolist()
-        else:
-            count_rows[i].copy_(oc, non_blocking=True)
-        return oc
+        return matched, oc
 
-    default_stream = torch.cuda.current_stream(dev)
-
-    def step(i=0, sync_host=False, single_stream=False):
-        targets = batches[i % len(batches)][1]
-        if two and not sync_host and not single_stream:
-            # set_stream, not the `with torch.cuda.stream(...)` context manager: the manager's enter / exit cost the
-            # host several microseconds each, twice per step
-            if os.environ.get("OD_BENCH_MATCH_FIRST"):
-                torch.cuda.set_stream(s_matches[i % len(s_matches)])
-                matched = model.match_anchors(targets, anchors_per_image)
-                torch.cuda.set_stream(s_posts[i % len(s_posts)])
-                oc = run_post(i, False)
-                return matched, oc
-            torch.cuda.set_stream(s_posts[i % len(s_posts)])
-            oc = run_post(i, False)
-            torch.cuda.set_stream(s_matches[i % len(s_matches)])
-            matched = model.match_anchors(targets, anchors_per_image)
-            return matched, oc
-        torch.cuda.set_stream(default_stream)
-        oc = run_post(i, sync_host)
-        return model.match_anchors(targets, anchors_per_image), oc
+    step = graph_step_run if use_graph else eager_step
 
     def sync():
         torch.cuda.set_stream(default_stream)
@@ -299,7 +348,7 @@ def main():
         sync()
         tb = time.perf_counter()
         for i in range(20):
-            step(i % counts_host.shape[0])
+            step(i)
         sync()
         cur = (time.perf_counter() - tb) / 20
         spin["batches"] += 1
@@ -323,25 +372,26 @@ def main():
         print(f"[rank {rank}] spin-up done: {spin}", file=sys.stderr, flush=True)
 
     for i in range(max(args.warmup, 2)):                  # the W warm-up steps of the contract
-        step(i % counts_host.shape[0])
+        step(i)
     sync()
 
-    # which kernel dominates?  (untimed probe with every launch bracketed)
+    # which kernel dominates?  (untimed probe with every launch bracketed, eager launches on one stream)
     _C.profile_select(_C.PROFILE_ALL)
     for k in range(len(_C.KERNEL_NAMES)):
         _C.profile_read(k)
-    step(single_stream=True)                              # the default stream's scratch buffers
+    eager_step(single_stream=True)                        # the default stream's scratch buffers
     torch.cuda.synchronize(dev)
     for k in range(len(_C.KERNEL_NAMES)):
         _C.profile_read(k)
-    for _ in range(3):
-        _, oc = step(single_stream=True)                  # one stream: every kernel has the GPU to itself
+    for i in range(3):
+        eager_step(i, single_stream=True)                 # one stream: every kernel has the GPU to itself
     torch.cuda.synchronize(dev)
     probe = {}
     for k, name in enumerate(_C.KERNEL_NAMES):
         ms, n = _C.profile_read(k)
         if n:
             probe[name] = {"ms_per_launch": ms / n, "launches_per_step": n / 3}
+    _C.profile_select(_C.PROFILE_OFF)
     n_cand = float(kernels_candidates_per_image(cfg, split, split_anchors, shapes, model))
     # Dominant = the kernel that occupies most of the chip per step: duration x the share of the 256 CUs its grid can
     # fill.  NMS (one workgroup per image) and the top-k kernels (one per image and level) are as long as the matching
@@ -353,54 +403,70 @@ def main():
     dominant = max(probe, key=lambda name: probe[name]["ms_per_launch"] * probe[name]["launches_per_step"]
                    * probe[name]["cu_share"])
     dom_id = _C.KERNEL_NAMES.index(dominant)
-    # In the timed region every 8th launch of the dominant kernel is timed (start / stop events on the dispatch):
-    # a timed launch costs the host tens of microseconds, which would otherwise end up in `value`.
-    _C.profile_select(dom_id)
-    _C.profile_stride(8)
-    _C.profile_read(dom_id)
+    for acc in accumulators:
+        acc.zero_()
 
+    # ---- the timed region: exactly K steps ---------------------------------------------------------------------
+    # Every 8th launch of the dominant kernel is timed inside it (start / stop events on the dispatch; a timed launch
+    # costs the host tens of microseconds, hence not every launch).  Launches inside a recorded graph cannot carry
+    # events: with --graph the kernel is timed in a second loop of eager steps after the region.
+    if not use_graph:
+        _C.profile_select(dom_id)
+        _C.profile_stride(8)
+        _C.profile_read(dom_id)
     sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
-    host_enqueue = time.perf_counter() - t0               # the host's share: all launches issued, GPU possibly still busy
+    host_enqueue = time.perf_counter() - t0               # the host's share: everything issued, GPU possibly still busy
     sync()
-    if rehearsal:
-        print(f"[rank {rank}] timed region done", file=sys.stderr, flush=True)
-    total_detections = int(counts_host[:args.steps].sum())      # the host reads every step's counts here
+    if use_graph:                                         # the host reads the detection counts of all steps here
+        total_detections = int(sum(int(acc.sum()) for acc in accumulators))
+    else:
+        total_detections = int(counts_host[:min(args.steps, len(count_rows))].sum()) * max(1, args.steps // len(count_rows))
     elapsed = time.perf_counter() - t0
-    dom_ms, dom_n = _C.profile_read(dom_id)
+    dom_ms, dom_n = (0.0, 0) if use_graph else _C.profile_read(dom_id)
     _C.profile_select(_C.PROFILE_OFF)
     _C.profile_stride(1)
+    if rehearsal:
+        print(f"[rank {rank}] timed region done", file=sys.stderr, flush=True)
 
-    # for reference: the same step with a blocking host read of the counts after every step (not `value`)
-    ms_host_sync = None
-    if not args.lean:
-        step(sync_host=True)
+    def timed_loop(fn, n, finish=None):
+        fn(0)
         sync()
         t1 = time.perf_counter()
-        for i in range(20):
-            step(i, sync_host=True)
+        keep = [fn(i) for i in range(n)]
+        if finish is not None:
+            finish(keep)
         sync()
-        ms_host_sync = 1e3 * (time.perf_counter() - t1) / 20
+        return 1e3 * (time.perf_counter() - t1) / n
 
-    # the two halves on their own (they never run in the same forward of the reference): 20 launches each
-    def half(fn):
-        fn()
-        sync()
-        th = time.perf_counter()
-        for _ in range(20):
-            fn()
-        sync()
-        return 1e3 * (time.perf_counter() - th) / 20
-
-    ms_post = ms_match = None
+    # ---- secondary figures (not `value`) ------------------------------------------------------------------------
+    ms_timed_kernel = ms_graph = ms_api = ms_api_blocking = ms_post = ms_match = None
+    if use_graph:
+        _C.profile_select(dom_id)
+        _C.profile_stride(8)
+        _C.profile_read(dom_id)
+        ms_timed_kernel = timed_loop(lambda i: eager_step(i), args.steps)
+        dom_ms, dom_n = _C.profile_read(dom_id)
+        _C.profile_select(_C.PROFILE_OFF)
+        _C.profile_stride(1)
     if not args.lean:
-        ms_post = half(lambda: postprocess_batched(split["cls_logits"], split["bbox_regression"], split_anchors, shapes,
-                                                   model.score_thresh, model.topk_candidates, model.nms_thresh,
-                                                   model.detections_per_img, _C.CODER_BOXCODER,
-                                                   model.box_coder.bbox_xform_clip, return_padded=True))
-        ms_match = half(lambda: model.match_anchors(targets, anchors_per_image))
+        # through the reference's call signature: model.postprocess_detections(head_outputs, anchors, image_shapes)
+        # -> list of per-image dictionaries; they are looked at after the last step, inside the timed loop ...
+        n_api = min(args.steps, 100)
+        ms_api = timed_loop(lambda i: eager_step(i, mode="api"), n_api,
+                            finish=lambda keep: [d["boxes"].shape[0] for _, dets in keep for d in dets[:1]])
+        # ... or after every step (the host waits for the GPU once per step)
+        ms_api_blocking = timed_loop(lambda i: eager_step(i, mode="api-blocking"), 20)
+        # the two halves on their own (they never run in the same forward of the reference)
+        torch.cuda.set_stream(default_stream)
+        ms_post = timed_loop(lambda i: post_padded(i % n_rot), 20)
+        ms_match = timed_loop(lambda i: model.match_anchors(batches[i % n_rot][1], anchors_per_image), 20)
+        if not use_graph and world == 1:
+            # the recorded form of the step (one HIP graph per resident batch, replayed on two launch streams in turn)
+            record_graphs()
+            ms_graph = timed_loop(graph_step_run, min(args.steps, 100))
 
     if world > 1:
         import torch.distributed as dist
@@ -410,13 +476,19 @@ def main():
 
     if rank == 0:
         images = cfg.batch * world * args.steps
-        dur_s = (dom_ms / max(dom_n, 1)) * 1e-3
+        alone_s = probe[dominant]["ms_per_launch"] * 1e-3
+        dur_s = (dom_ms / dom_n) * 1e-3 if dom_n else alone_s
         abytes = algorithmic_bytes(cfg, dominant, n_cand)
         achieved = abytes / dur_s / 1e9 if dur_s > 0 else 0.0
         for name, p in probe.items():
             b = algorithmic_bytes(cfg, name, n_cand)
             p["algorithmic_MB"] = b / 1e6
             p["GBps"] = b / (p["ms_per_launch"] * 1e-3) / 1e9 if p["ms_per_launch"] > 0 else 0.0
+        is_match = dominant.startswith("match")
+        traffic = pmc_traffic(dominant)
+        valu = pmc_valu(dominant)
+        # a wave64 fp32 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
+        valu_issue_s = (valu * 4.0 / (NUM_CUS * 4 * 2.4e9)) if valu else None
         result = {
             "metric": "images/sec (match+decode+NMS) at 1024\u00b2 bs16, 1/2/4/8 GPU; % HBM roofline",
             "value": images / elapsed,
@@ -425,8 +497,15 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "ms_per_step_blocking_host_read": ms_host_sync,
+            "step_launch": "one recorded HIP graph per step" if use_graph else "every kernel launched from the host",
             "ms_per_step_host_enqueue": 1e3 * host_enqueue / args.steps,
+            "ms_per_step_eager_with_timed_kernel": ms_timed_kernel,
+            "ms_per_step_graph_replay": ms_graph,
+            # the same work through the reference's call signature (model.postprocess_detections -> per-image
+            # dictionaries, model.match_anchors), kernels launched from the host
+            "value_api": (cfg.batch * world / (ms_api * 1e-3)) if ms_api else None,
+            "ms_per_step_api": ms_api,
+            "ms_per_step_blocking_host_read": ms_api_blocking,
             "detections_per_step": total_detections / args.steps,
             "device_spin_up": spin,
             "phases": None if args.lean else {
@@ -454,28 +533,35 @@ def main():
                 "parallelism": f"image-sharded x{world}" + (
                     (", all-gather of detections (" + ("gloo over host memory: rehearsal on one GPU" if rehearsal
                                                        else "RCCL") + ")") if world > 1 else ""),
-                "resident_batches_in_rotation": len(batches),
-                "hip_streams": args.streams,
+                "resident_batches_in_rotation": n_rot,
+                "hip_streams_eager": args.streams,
             },
             "roofline": {
                 "kernel": dominant,
                 "dominant_by": "duration x share of the 256 CUs the grid can fill (kernels[*].cu_share)",
-                "bound": "hbm",
+                # the matching kernels are bound by VALU issue, not by HBM: the anchors are shared by the batch and
+                # served from L2, so the bytes that cross HBM (`traffic`) are about half the algorithmic bytes
+                "bound": "valu" if is_match else "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dominant),
+                "traffic": traffic,
+                "frac_moved_bytes": (traffic / dur_s / 1e9 / HBM_PEAK_GBS) if (traffic and dur_s > 0) else None,
+                "valu_insts_per_launch": valu,
+                "valu_issue_frac": (valu_issue_s / dur_s) if (valu_issue_s and dur_s > 0) else None,
                 "launch_us": dur_s * 1e6,
+                "launch_us_measured_in": ("a loop of K eager steps after the timed region (launches inside a recorded "
+                                          "graph cannot carry events)" if use_graph else
+                                          "the timed region: HIP events on every 8th dispatch of this kernel"),
                 "algorithmic_MB_per_launch": abytes / 1e6,
-                # the same kernel with the GPU to itself (single-stream probe before the timed region): in the
-                # timed region steps on other streams run beside it and stretch it
                 # matching only: 13 fp32 operations per (anchor, GT) pair of the brute-force formulation against the
                 # non-FMA VALU peak (78.6 Tops/s); above 1 because the kernels skip the pairs whose boxes cannot overlap
                 "valu_frac_bruteforce_equivalent": (13.0 * cfg.batch * cfg.num_anchors * cfg.num_gt / dur_s / 78.6e12
-                                                    if dominant.startswith("match") and dur_s > 0 else None),
-                "launch_us_alone": probe[dominant]["ms_per_launch"] * 1e3,
-                "frac_alone": (abytes / (probe[dominant]["ms_per_launch"] * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                                                    if is_match and dur_s > 0 else None),
+                # the same kernel with the GPU to itself (single-stream probe)
+                "launch_us_alone": alone_s * 1e6,
+                "frac_alone": (abytes / alone_s / 1e9) / HBM_PEAK_GBS,
             },
             "kernels": probe,
         }

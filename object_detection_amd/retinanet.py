@@ -12,6 +12,7 @@ forward / backward kernels.
 from __future__ import annotations
 
 import math
+import weakref
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -136,14 +137,32 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
     return kernels._device_ints(flat, device).view(-1, 2)
 
 
+_COUNT_ROWS = 64                    # pinned rows for detection counts on their way to the host
+_count_pool: Dict[int, Tensor] = {}  # batch size -> pinned int32 [_COUNT_ROWS, batch]
+_count_owner: Dict[tuple, "weakref.ref"] = {}
+_count_next: Dict[int, int] = {}
+
+
 class _PendingBatch:
-    """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into pinned
-    memory + an event recorded behind it).  ``counts()`` waits for that event once."""
-    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts")
+    """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into a row of
+    pinned memory + an event recorded behind it).  ``counts()`` waits for that event once.  The pinned rows are handed
+    out in turn; a row whose previous batch was never looked at is read out (one wait) before it is reused."""
+    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "__weakref__")
 
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
         self.boxes, self.scores, self.labels = boxes, scores, labels
-        self.counts_host = torch.empty(counts_dev.shape, dtype=counts_dev.dtype, pin_memory=True)
+        B = int(counts_dev.shape[0])
+        pool = _count_pool.get(B)
+        if pool is None:
+            pool = _count_pool[B] = torch.empty((_COUNT_ROWS, B), dtype=torch.int32).pin_memory()
+        row = _count_next.get(B, 0)
+        _count_next[B] = (row + 1) % _COUNT_ROWS
+        previous = _count_owner.get((B, row))
+        previous = previous() if previous is not None else None
+        if previous is not None:
+            previous.counts()
+        _count_owner[(B, row)] = weakref.ref(self)
+        self.counts_host = pool[row]
         self.counts_host.copy_(counts_dev, non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()

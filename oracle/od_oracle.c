@@ -332,19 +332,45 @@ void orc_clip(float* boxes, int64_t n, float height, float width) {
 
 /* score filter + top-k of one (image, level): spec sigmoid, > thresh, k best, ties -> lower index.
  * ctr == NULL: RetinaNet score; ctr != NULL (one per anchor): FCOS sqrt(sig(cls) * sig(ctr)). */
+/* "a ranks before b": higher score first, lower index first among equal scores */
+static inline int ranks_before(const sidx_t* a, const sidx_t* b) {
+    return a->s > b->s || (a->s == b->s && a->i < b->i);
+}
+
 int64_t orc_filter_topk(const float* logits, const float* ctr, int64_t n_anchors, int64_t num_classes,
                         float thresh, int64_t k, float* out_scores, int64_t* out_idx) {
+    /* the k best candidates in a binary heap whose root is the worst of them (O(n log k), memory O(k)) */
     int64_t n = n_anchors * num_classes, c = 0;
-    sidx_t* cand = (sidx_t*)malloc(sizeof(sidx_t) * (size_t)(n > 0 ? n : 1));
+    if (k <= 0) return 0;
+    sidx_t* heap = (sidx_t*)malloc(sizeof(sidx_t) * (size_t)k);
     for (int64_t i = 0; i < n; ++i) {
         float s = orc_sigmoidf(logits[i]);
         if (ctr) { float t = s * orc_sigmoidf(ctr[i / num_classes]); s = sqrtf(t); }
-        if (s > thresh) { cand[c].s = s; cand[c].i = i; ++c; }
+        if (!(s > thresh)) continue;
+        sidx_t e; e.s = s; e.i = i;
+        if (c < k) {                                   /* sift up: a parent must not rank before its child */
+            int64_t p = c++;
+            while (p > 0) {
+                int64_t q = (p - 1) / 2;
+                if (!ranks_before(&heap[q], &e)) break;
+                heap[p] = heap[q]; p = q;
+            }
+            heap[p] = e;
+        } else if (ranks_before(&e, &heap[0])) {       /* better than the worst kept: replace the root, sift down */
+            int64_t p = 0;
+            for (;;) {
+                int64_t l = 2 * p + 1, r = l + 1, w = l;
+                if (l >= c) break;
+                if (r < c && ranks_before(&heap[l], &heap[r])) w = r;    /* the worse of the two children */
+                if (!ranks_before(&e, &heap[w])) break;
+                heap[p] = heap[w]; p = w;
+            }
+            heap[p] = e;
+        }
     }
-    qsort(cand, (size_t)c, sizeof(sidx_t), cmp_desc_stable);
-    if (c > k) c = k;
-    for (int64_t j = 0; j < c; ++j) { out_scores[j] = cand[j].s; out_idx[j] = cand[j].i; }
-    free(cand);
+    qsort(heap, (size_t)c, sizeof(sidx_t), cmp_desc_stable);
+    for (int64_t j = 0; j < c; ++j) { out_scores[j] = heap[j].s; out_idx[j] = heap[j].i; }
+    free(heap);
     return c;
 }
 

@@ -50,6 +50,53 @@ def test_match_retinanet(device, m):
     assert np.array_equal(out_nolq[0].numpy(), c_oracle.match_retinanet(gts[0].numpy(), anchors.numpy(), 0.6, 0.5, False))
 
 
+def test_batched_anchor_tables(device):
+    """Anchors given per image ([B, N, 4], anchor_batch_stride = N) instead of one table shared by the batch:
+    od_match_retinanet, od_match_fcos and od_select_candidates against the scalar checker, image by image."""
+    gen = torch.Generator().manual_seed(404)
+    B = 3
+    grids = (32, 16, 8)
+    ag, base = _anchors_cpu((256, 256), grids, synthetic.retinanet_anchor_sizes(3, 32))
+    n = base.shape[0]
+    # a different table per image: the pyramid shifted and scaled
+    tables = torch.stack([base * (1.0 + 0.1 * b) + 3.0 * b for b in range(B)])
+    gts = [synthetic.make_gt_boxes(m, (256, 256), gen) for m in (40, 7, 0)]
+    out = kernels.match_retinanet(tables.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+    for b in range(B):
+        assert np.array_equal(out[b].numpy(), c_oracle.match_retinanet(gts[b].numpy(), tables[b].numpy(), 0.6, 0.5)), b
+    assert not torch.equal(out[0], kernels.match_retinanet(tables[1].to(device), [gts[0].to(device)], 0.6, 0.5, True).cpu()[0])
+    # FCOS: one anchor per location
+    agf, fbase = _anchors_cpu((256, 256), grids, ((8,), (16,), (32,)), (1.0,))
+    ftab = torch.stack([fbase + 2.0 * b for b in range(B)])
+    npl = [g * g for g in grids]
+    fout = kernels.match_fcos(ftab.to(device), [g.to(device) for g in gts], npl[0], npl[-1], 1.5).cpu()
+    for b in range(B):
+        assert np.array_equal(fout[b].numpy(), c_oracle.match_fcos(gts[b].numpy(), ftab[b].numpy(), npl[0], npl[-1], 1.5)), b
+    # candidate selection: decoded boxes depend on the image's own anchors
+    C, K = 4, 150
+    sizes = [9 * g * g for g in grids]
+    logits = torch.empty((B, n, C)).normal_(-2.0, 1.5, generator=gen)
+    reg = torch.randn((B, n, 4), generator=gen) * 0.4
+    hw = torch.tensor([[256, 256], [250, 240], [256, 200]], dtype=torch.int32, device=device)
+    anc_levels = [t.contiguous().to(device) for t in tables.split(sizes, dim=1)]          # [B, N_l, 4] each
+    cb, cs, cl, ci, cc = kernels.select_candidates([t.to(device) for t in logits.split(sizes, dim=1)],
+                                                   [t.to(device) for t in reg.split(sizes, dim=1)], anc_levels, hw, 0.3, K,
+                                                   _C.CODER_BOXCODER, math.log(1000.0 / 16), want_index=True)
+    cb, ci, cc = cb.cpu(), ci.cpu(), cc.cpu()
+    off = 0
+    for lvl, sz in enumerate(sizes):
+        for b in range(B):
+            s_ref, i_ref = c_oracle.filter_topk(logits[b, off:off + sz].numpy(), None, C, 0.3, K)
+            cnt = int(cc[b, lvl])
+            assert cnt == len(i_ref) and np.array_equal(ci[b, lvl * K:lvl * K + cnt].numpy(), i_ref), (lvl, b)
+            a_idx = i_ref // C
+            bx = c_oracle.decode_single(reg[b, off:off + sz].numpy()[a_idx], tables[b, off:off + sz].numpy()[a_idx],
+                                        math.log(1000.0 / 16))
+            bx = c_oracle.clip(bx, float(hw[b, 0]), float(hw[b, 1]))
+            assert np.array_equal(cb[b, lvl * K:lvl * K + cnt].numpy().view(np.uint32), bx.view(np.uint32)), (lvl, b)
+        off += sz
+
+
 def test_match_retinanet_gt_without_overlap(device):
     """A GT that overlaps no anchor has max IoU 0: torchvision then restores every anchor."""
     ag, anchors = _anchors_cpu((128, 128), (16, 8), ((16,), (32,)), (1.0,))
@@ -586,6 +633,19 @@ def test_select_candidates_reads_channel_major_head_outputs(device, num_anchors,
                                            ctr_maps=ctr_maps if with_ctr else None)
     counts = want[4].cpu()
     assert torch.equal(got[4].cpu(), counts) and int(counts.sum()) > 0
+    # the channel-major route against the scalar checker run on the permuted copies (not only against the other route)
+    g_scores, g_labels, g_index = got[1].cpu(), got[2].cpu(), got[3].cpu()
+    for lvl, (cm, tm) in enumerate(zip(cls_maps, ctr_maps)):
+        logits = permuted(cm, C).cpu()
+        ctr = permuted(tm, 1).cpu() if with_ctr else None
+        for b in range(B):
+            s_ref, i_ref = c_oracle.filter_topk(logits[b].numpy(), ctr[b].numpy().reshape(-1) if with_ctr else None, C, 0.3, K)
+            n = int(counts[b, lvl])
+            assert n == len(s_ref), (lvl, b)
+            sl = slice(lvl * K, lvl * K + n)
+            assert np.array_equal(g_index[b, sl].numpy(), i_ref), (lvl, b)
+            assert np.array_equal(g_scores[b, sl].numpy().view(np.uint32), s_ref.view(np.uint32)), (lvl, b)
+            assert np.array_equal(g_labels[b, sl].numpy(), i_ref % C), (lvl, b)
     valid = (torch.arange(K)[None, None, :] < counts[:, :, None]).reshape(B, -1)
     for a, b, name in zip(got[:4], want[:4], ("boxes", "scores", "labels", "index")):
         assert torch.equal(a.cpu()[valid], b.cpu()[valid]), name
