@@ -283,7 +283,7 @@ def main():
         else:
             out = model.postprocess_detections(batches[r][0], split_anchors, shapes)
             if mode == "api-blocking":
-                out[0]["boxes"]
+                [(d["boxes"], d["scores"], d["labels"]) for d in out]
         torch.cuda.set_stream(default_stream if single_stream or not two else s_matches[i % len(s_matches)])
         matched = model.match_anchors(batches[r][1], anchors_per_image)
         return matched, out
@@ -431,18 +431,25 @@ def main():
     if rehearsal:
         print(f"[rank {rank}] timed region done", file=sys.stderr, flush=True)
 
-    def timed_loop(fn, n, finish=None):
+    def timed_loop(fn, n, consume=None, lag=8):
+        """ms per call of fn(i), i < n.  `consume(result)` is applied to every result `lag` calls after it was produced
+        (a consumer that runs a few steps behind the GPU), to the last ones after the loop."""
+        from collections import deque
         fn(0)
         sync()
+        pending = deque()
         t1 = time.perf_counter()
-        keep = [fn(i) for i in range(n)]
-        if finish is not None:
-            finish(keep)
+        for i in range(n):
+            pending.append(fn(i))
+            if consume is not None and len(pending) > lag:
+                consume(pending.popleft())
+        while consume is not None and pending:
+            consume(pending.popleft())
         sync()
         return 1e3 * (time.perf_counter() - t1) / n
 
     # ---- secondary figures (not `value`) ------------------------------------------------------------------------
-    ms_timed_kernel = ms_graph = ms_api = ms_api_blocking = ms_post = ms_match = None
+    ms_timed_kernel = ms_graph = ms_api = ms_api_deferred = ms_api_blocking = ms_post = ms_match = None
     if use_graph:
         _C.profile_select(dom_id)
         _C.profile_stride(8)
@@ -452,12 +459,14 @@ def main():
         _C.profile_select(_C.PROFILE_OFF)
         _C.profile_stride(1)
     if not args.lean:
-        # through the reference's call signature: model.postprocess_detections(head_outputs, anchors, image_shapes)
-        # -> list of per-image dictionaries; they are looked at after the last step, inside the timed loop ...
+        # Through the reference's call signature: model.postprocess_detections(head_outputs, anchors, image_shapes) ->
+        # list of per-image dictionaries, which are cut to size when first looked at.  `api`: a consumer looks at
+        # the tensors of every image eight steps after the call (by then the counts have arrived: no wait);
+        # `api_deferred`: nobody looks inside the loop; `blocking`: the host looks right after every call.
         n_api = min(args.steps, 100)
-        ms_api = timed_loop(lambda i: eager_step(i, mode="api"), n_api,
-                            finish=lambda keep: [d["boxes"].shape[0] for _, dets in keep for d in dets[:1]])
-        # ... or after every step (the host waits for the GPU once per step)
+        look = lambda res: [(d["boxes"], d["scores"], d["labels"]) for d in res[1]]
+        ms_api = timed_loop(lambda i: eager_step(i, mode="api"), n_api, consume=look)
+        ms_api_deferred = timed_loop(lambda i: eager_step(i, mode="api"), n_api, consume=lambda res: None, lag=32)
         ms_api_blocking = timed_loop(lambda i: eager_step(i, mode="api-blocking"), 20)
         # the two halves on their own (they never run in the same forward of the reference)
         torch.cuda.set_stream(default_stream)
@@ -505,6 +514,7 @@ def main():
             # dictionaries, model.match_anchors), kernels launched from the host
             "value_api": (cfg.batch * world / (ms_api * 1e-3)) if ms_api else None,
             "ms_per_step_api": ms_api,
+            "ms_per_step_api_deferred": ms_api_deferred,
             "ms_per_step_blocking_host_read": ms_api_blocking,
             "detections_per_step": total_detections / args.steps,
             "device_spin_up": spin,

@@ -147,7 +147,7 @@ class _PendingBatch:
     """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into a row of
     pinned memory + an event recorded behind it).  ``counts()`` waits for that event once.  The pinned rows are handed
     out in turn; a row whose previous batch was never looked at is read out (one wait) before it is reused."""
-    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "__weakref__")
+    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "__weakref__")
 
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
         self.boxes, self.scores, self.labels = boxes, scores, labels
@@ -167,12 +167,19 @@ class _PendingBatch:
         self.event = torch.cuda.Event()
         self.event.record()
         self._counts = None
+        self._rows = None
 
     def counts(self) -> List[int]:
         if self._counts is None:
             self.event.synchronize()
             self._counts = self.counts_host.tolist()
         return self._counts
+
+    def rows(self):
+        """Per-image views of the padded outputs (one unbind per tensor for the whole batch)."""
+        if self._rows is None:
+            self._rows = (self.boxes.unbind(0), self.scores.unbind(0), self.labels.unbind(0))
+        return self._rows
 
 
 class Detections(dict):
@@ -201,10 +208,11 @@ class Detections(dict):
             return
         self._pending = None
         i, c = self._index, p.counts()[self._index]
-        boxes = p.boxes[i, :c]
+        rb, rs, rl = p.rows()
+        boxes = rb[i].narrow(0, 0, c)
         if self._scale is not None:
             boxes = boxes * self._scale
-        dict.update(self, boxes=boxes, scores=p.scores[i, :c], labels=p.labels[i, :c])
+        dict.update(self, boxes=boxes, scores=rs[i].narrow(0, 0, c), labels=rl[i].narrow(0, 0, c))
 
     def __getitem__(self, key):
         self._materialize()

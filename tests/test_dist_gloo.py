@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -50,4 +51,53 @@ def test_all_gather_detections_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, total, d, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _gpu_worker(rank, world, port, ret):
+    """Both ranks on GPU 0 (a one-GPU machine), exchange over gloo: the image-sharded inference tail -- NMS of the
+    rank's own images, od_pack_detections, one all-gather, unpack -- against the NMS of the whole batch."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from object_detection_amd import _C, kernels
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(11)                     # the same global batch on every rank
+    B, segs, stride, D = 6, 3, 200, 120
+    n = segs * stride
+    xy = torch.rand((B, n, 2), generator=gen) * 300
+    boxes = torch.cat([xy, xy + torch.rand((B, n, 2), generator=gen) * 60 + 1], dim=2)
+    scores = torch.rand((B, n), generator=gen).view(B, segs, stride).sort(dim=2, descending=True)[0].reshape(B, n)
+    labels = torch.randint(0, 5, (B, n), generator=gen, dtype=torch.int32)
+    counts = torch.randint(50, stride + 1, (B, segs), generator=gen, dtype=torch.int32)
+    full = [t.to(dev) for t in (boxes, scores, labels, counts)]
+    _, fb, fs, fl, fc = kernels.batched_nms_padded(*full, stride, True, 0.4, _C.NMS_AUTO_GPU, D, want_keep_idx=False)
+    lo, hi = sharding.shard_bounds(B, rank, world)
+    _, ob, os_, ol, oc = kernels.batched_nms_padded(*[t[lo:hi].contiguous() for t in full], stride, True, 0.4,
+                                                    _C.NMS_AUTO_GPU, D, want_keep_idx=False)
+    ok = True
+    for reuse in (False, True, True):
+        packed, cnt = sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=reuse)
+        ok = ok and packed.is_cuda and tuple(packed.shape) == (B, D, 6)
+        ok = ok and torch.equal(cnt.to(torch.int32), fc)
+        ok = ok and torch.equal(packed[..., :4], fb) and torch.equal(packed[..., 4], fs)
+        ok = ok and torch.equal(packed[..., 5].to(torch.int64), fl)
+    dets = sharding.unpack_detections(packed, cnt)
+    ok = ok and all(torch.equal(d["boxes"], fb[i, :int(fc[i])]) and torch.equal(d["labels"], fl[i, :int(fc[i])])
+                    for i, d in enumerate(dets))
+    ok = ok and int(fc.min()) > 0
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_inference_tail_on_gpu_world2():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
