@@ -147,7 +147,7 @@ class _PendingBatch:
     """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into a row of
     pinned memory + an event recorded behind it).  ``counts()`` waits for that event once.  The pinned rows are handed
     out in turn; a row whose previous batch was never looked at is read out (one wait) before it is reused."""
-    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "__weakref__")
+    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "members", "__weakref__")
 
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
         self.boxes, self.scores, self.labels = boxes, scores, labels
@@ -168,6 +168,7 @@ class _PendingBatch:
         self.event.record()
         self._counts = None
         self._rows = None
+        self.members = ()                   # weak references to the Detections of the batch that are not filled yet
 
     def counts(self) -> List[int]:
         if self._counts is None:
@@ -176,17 +177,37 @@ class _PendingBatch:
         return self._counts
 
     def rows(self):
-        """Per-image views of the padded outputs (one unbind per tensor for the whole batch)."""
+        """Per-image (boxes [d, 4], scores [d], labels [d]) views cut to size, made for the whole batch at the first
+        request: one split of each flattened padded tensor into (kept, padding) pieces per image -- three calls into
+        torch instead of three slices per image."""
         if self._rows is None:
-            self._rows = (self.boxes.unbind(0), self.scores.unbind(0), self.labels.unbind(0))
+            counts = self.counts()
+            B, D = int(self.scores.shape[0]), int(self.scores.shape[1])
+            sizes = [0] * (2 * B)
+            sizes[0::2] = counts
+            sizes[1::2] = [D - c for c in counts]
+            self._rows = (self.boxes.reshape(B * D, 4).split_with_sizes(sizes)[0::2],
+                          self.scores.reshape(B * D).split_with_sizes(sizes)[0::2],
+                          self.labels.reshape(B * D).split_with_sizes(sizes)[0::2])
         return self._rows
+
+
+class _ReadyDetections(dict):
+    """What a ``Detections`` object becomes once its tensors are cut out: a plain dictionary again (no Python-level
+    method between the caller and ``dict``), which keeps answering ``defer_box_scale`` with False."""
+
+    __hash__ = None
+
+    def defer_box_scale(self, scale: Tensor) -> bool:
+        return False
 
 
 class Detections(dict):
     """``{"boxes": [d, 4], "scores": [d], "labels": [d]}`` of one image, as ``postprocess_detections`` returns it.  The
     number of detections d is only known on the GPU when the call returns; the three tensors are cut out of the padded
-    outputs of the batch at the first access to the dictionary, which waits for the counts of the batch (one
-    event) -- the call itself never makes the host wait for the GPU."""
+    outputs of the batch at the first access to the dictionary of ANY image of the batch, which waits for the counts of
+    the batch (one event) and fills the dictionaries of all its images -- the call itself never makes the host wait
+    for the GPU.  A filled dictionary turns into a plain ``dict`` subclass without overridden accessors."""
 
     def __init__(self, pending: _PendingBatch, index: int):
         super().__init__()
@@ -202,17 +223,26 @@ class Detections(dict):
         self._scale = scale if self._scale is None else self._scale * scale
         return True
 
+    def _fill(self, boxes: Tensor, scores: Tensor, labels: Tensor) -> None:
+        if self._pending is None:
+            return
+        self._pending = None
+        if self._scale is not None:
+            boxes = boxes * self._scale
+        dict.update(self, boxes=boxes, scores=scores, labels=labels)
+        self.__class__ = _ReadyDetections
+
     def _materialize(self) -> None:
         p = self._pending
         if p is None:
             return
-        self._pending = None
-        i, c = self._index, p.counts()[self._index]
         rb, rs, rl = p.rows()
-        boxes = rb[i].narrow(0, 0, c)
-        if self._scale is not None:
-            boxes = boxes * self._scale
-        dict.update(self, boxes=boxes, scores=rs[i].narrow(0, 0, c), labels=rl[i].narrow(0, 0, c))
+        for ref in p.members:                    # every image of the batch that is still alive, this one included
+            d = ref()
+            if d is not None:
+                i = d._index
+                d._fill(rb[i], rs[i], rl[i])
+        p.members = ()
 
     def __getitem__(self, key):
         self._materialize()
@@ -306,7 +336,9 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
     if return_padded:
         return ob, os_, ol, oc
     pending = _PendingBatch(ob, os_, ol, oc)
-    return [Detections(pending, i) for i in range(ob.shape[0])]
+    out = [Detections(pending, i) for i in range(ob.shape[0])]
+    pending.members = [weakref.ref(d) for d in out]
+    return out
 
 
 class RetinaNet(nn.Module):

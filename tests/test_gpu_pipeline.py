@@ -404,8 +404,8 @@ def test_full_size_cfg2_two_images_and_batch_properties(device):
 
 def test_full_size_cfg4_selection_properties(device):
     """One image of the largest configuration (1536 x 1536, 1 769 040 anchors, 91 classes, score threshold 0.05: 161 M
-    logits, about half of them above the threshold) -- too large for the CPU checker, so the candidate selection is
-    checked through properties that hold at any size, evaluated with torch on the GPU: per level the candidates are
+    logits, about half of them above the threshold).  The candidate selection is checked through properties that
+    hold at any size, evaluated with torch on the GPU, and then bit for bit against the scalar C checker: per level the candidates are
     sorted (score descending, flat index ascending on ties), their scores are the sigmoid of the logits they point
     at (1e-6), there are min(K, #passing) of them, and no logit outside the selection scores higher than the last
     one selected.  The detections are capped, sorted, inside the image and stable under a second NMS."""

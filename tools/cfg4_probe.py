@@ -1,4 +1,5 @@
-"""Timing of the candidate selection in the dense regime: 1536x1536, 91 classes, score threshold 0.05, one image."""
+"""Timing of the candidate selection in the dense regime: 1536x1536, 91 classes, score threshold 0.05.
+Usage: cfg4_probe.py [images [topk_candidates]]"""
 import dataclasses
 import json
 import os
@@ -30,8 +31,8 @@ def main():
     reg = torch.randn((cfg.batch, n, 4), generator=g, device=dev) * 0.5
     cls_l, reg_l, anc_l = list(cls.split(sizes, 1)), list(reg.split(sizes, 1)), list(anchors.split(sizes))
     hw = _image_hw_tensor([cfg.image_size] * cfg.batch, dev)
-    K = cfg.topk_candidates
-    res = {}
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else cfg.topk_candidates
+    res = {"images": cfg.batch, "topk_candidates": K}
     for thr in (0.05, 0.5):
         sel = lambda: kernels.select_candidates(cls_l, reg_l, anc_l, hw, thr, K, _C.CODER_BOXCODER, 4.135)
         res[f"thr{thr}"] = timed(sel, reps=3, warm=1)
