@@ -226,8 +226,10 @@ def main():
     sizes = synthetic.level_sizes(cfg)
     grids = [(g, g) for g in cfg.grids]
     strides = [(cfg.image_size[0] // g, cfg.image_size[1] // g) for g in cfg.grids]
-    anchors_l = model.anchor_generator.grid_anchors(grids, strides, dev)
-    anchors_flat = torch.cat(anchors_l) if len(anchors_l) > 1 else anchors_l[0]
+    # the tensor AnchorGenerator.forward hands to compute_loss for every image (it carries the generator's note about
+    # the order of the anchor list, which the matching kernels use to form their tiles), and its per-level views
+    anchors_flat, _ = model.anchor_generator._grid_anchors_flat(grids, strides, dev)
+    anchors_l = list(anchors_flat.split(sizes))
     assert anchors_flat.shape[0] == cfg.num_anchors
     # Several resident batches, used in rotation: a step never finds its logits, regression values or GT boxes in the
     # 256 MiB last-level cache because an earlier step left them there (one batch is 403 MB of head outputs).

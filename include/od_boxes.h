@@ -79,6 +79,19 @@ int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_
                        const int32_t* gt_offsets, int64_t m_total, int32_t batch, float high, float low,
                        int32_t allow_low_quality, int64_t* matched, void* workspace, size_t workspace_bytes,
                        void* stream);
+/*
+ * The same call with a hint about the order of the anchor list: anchor_grids (host) holds num_grids triples
+ * (first, row_len, rows) saying that anchors [first, first + row_len * rows) are `rows` rows of `row_len` anchors with
+ * neighbouring rows spatially adjacent -- a pyramid level as torchvision's AnchorGenerator.grid_anchors emits it
+ * (order y, x, a: row_len = grid_w * anchors per location, rows = grid_h; anchor_utils.py of torchvision 0.16.2).
+ * The kernels then form their 256-anchor tiles from 4 rows x 64 anchors instead of 256 consecutive ones wherever a grid
+ * allows it (first a multiple of 256, row_len of 64, rows of 4), which tightens the tiles' bounding boxes; other grids
+ * are ignored.  Results do not depend on the hint.  Grids must be ascending, disjoint and inside [0, n) (OD_ERR_ARG).
+ */
+int od_match_retinanet_grids(const float* anchors, int64_t anchor_batch_stride, int64_t n, const int64_t* anchor_grids,
+                             int32_t num_grids, const float* gt_boxes, const int32_t* gt_offsets, int64_t m_total,
+                             int32_t batch, float high, float low, int32_t allow_low_quality, int64_t* matched,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * FCOS centre-sampling matcher.  Replaces the matching loop of torchvision FCOS.compute_loss

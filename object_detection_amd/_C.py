@@ -37,6 +37,8 @@ SIGNATURES = {
     "od_match_retinanet_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int64]),
     "od_match_retinanet": (c_int32, [_P, c_int64, c_int64, _P, _P, c_int64, c_int32, c_float, c_float, c_int32,
                                      _P, _P, c_size_t, _P]),
+    "od_match_retinanet_grids": (c_int32, [_P, c_int64, c_int64, _P, c_int32, _P, _P, c_int64, c_int32, c_float, c_float,
+                                           c_int32, _P, _P, c_size_t, _P]),
     "od_match_fcos": (c_int32, [_P, c_int64, c_int64, c_int64, c_int64, _P, _P, c_int32, c_float, _P, _P]),
     "od_box_iou": (c_int32, [_P, c_int64, _P, c_int64, _P, _P]),
     "od_matcher_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -29,12 +29,17 @@
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
+#include <string.h>
+
 namespace {
 
 using namespace od;
 
 constexpr int MT = 256;          // threads per workgroup = 4 independent waves
-constexpr int R = 4;             // anchors per lane
+#ifndef OD_R
+#define OD_R 4
+#endif
+constexpr int R = OD_R;          // anchors per lane
 constexpr int WTILE = 64 * R;    // anchors per wave
 constexpr int HEAVY = 24;        // a wave tile meeting more GT than this goes to the cooperative kernel
 constexpr int LCAP = HEAVY;      // entries of a light wave tile: one per GT with positive IoU
@@ -79,17 +84,54 @@ __device__ __forceinline__ int get_argmax(const MatchWs& ws, long long i) {
 __device__ __forceinline__ long long entry_base(int b, int m0) { return (long long)HCAP_PER_GT * m0 + 256ll * b; }
 __device__ __forceinline__ long long entry_cap(int M) { return (long long)HCAP_PER_GT * M + 256; }
 
+// Which 256 anchors form wave tile `wt`.  By default the consecutive ones.  Where the caller has said that a range of
+// the anchor list is a grid (`rows` rows of `row_len` anchors, neighbouring rows spatially adjacent: a pyramid level in
+// (y, x, a) order) and the range fits (start a multiple of 256, row_len a multiple of 64, rows a multiple of R), a tile
+// is R rows x 64 anchors instead: R runs of 64 consecutive anchors, one below the other.  Its bounding box is a
+// fraction as wide, so it meets fewer GT (finest level of a 1024 x 1024 image: 2.2 -> 1.3 GT per tile), and the loads
+// and stores stay 1 KiB / 512 B runs.  Any assignment of anchors to tiles gives the same results; the tile numbers
+// [0, wtiles) and the number of anchors per tile do not change.
+constexpr int MAX_GRIDS = 8;
+struct TileLayout {
+    int grids;                       // 0: consecutive tiles everywhere
+    int tile_begin[MAX_GRIDS];       // first wave tile of the grid
+    int tile_end[MAX_GRIDS];         // one past its last
+    int runs[MAX_GRIDS];             // 64-anchor runs per row (row_len / 64)
+    float inv_runs[MAX_GRIDS];
+    int row_len[MAX_GRIDS];
+};
+
+// first anchor of each of the R runs of wave tile wt (wave-uniform)
+__device__ __forceinline__ void tile_runs(const TileLayout& L, int wt, long long (&first)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) first[r] = (long long)wt * WTILE + r * 64;
+#pragma unroll
+    for (int l = 0; l < MAX_GRIDS; ++l) {
+        if (l < L.grids && wt >= L.tile_begin[l] && wt < L.tile_end[l]) {
+            const int tl = wt - L.tile_begin[l];
+            int bi = (int)((float)tl * L.inv_runs[l]);           // tl / runs, corrected below (tl < 2^24)
+            if (bi * L.runs[l] > tl) --bi;
+            if ((bi + 1) * L.runs[l] <= tl) ++bi;
+            const int bj = tl - bi * L.runs[l];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                first[r] = (long long)L.tile_begin[l] * WTILE + (long long)(R * bi + r) * L.row_len[l] + 64 * bj;
+        }
+    }
+}
+
 struct WaveTile {
     float ax1[R], ay1[R], ax2[R], ay2[R], aarea[R];
     float bx1, by1, bx2, by2;    // bounding box of the wave's anchors (wave-uniform)
 };
 
-__device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __restrict__ A, long long base, long long n) {
+__device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __restrict__ A, const long long (&first)[R],
+                                               long long n) {
     const int lane = threadIdx.x & 63;
     float bx1 = __builtin_inff(), by1 = __builtin_inff(), bx2 = -__builtin_inff(), by2 = -__builtin_inff();
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        long long idx = base + r * 64 + lane;
+        long long idx = first[r] + lane;
         if (idx > n - 1) idx = n - 1;               // out-of-range lanes replay the last anchor
         const float4 a = A[idx];
         t.ax1[r] = a.x; t.ay1[r] = a.y; t.ax2[r] = a.z; t.ay2[r] = a.w;
@@ -173,7 +215,7 @@ __device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1
 }
 
 __global__ __launch_bounds__(MT) void match_assign_kernel(
-    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles,
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
     const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
     float high, float low, long long* __restrict__ matched) {
     const int lane = threadIdx.x & 63;
@@ -181,7 +223,8 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
     // coarse (GT-heavy) pyramid levels sit at the end of the anchor list: start them first
     const int wt = wtiles - 1 - (int)(blockIdx.x * (MT / 64) + (threadIdx.x >> 6));
     if (wt < 0) return;
-    const long long base = (long long)wt * WTILE;
+    long long first[R];
+    tile_runs(layout, wt, first);
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     long long* out = matched + (long long)b * n;
@@ -190,7 +233,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
     if (M <= 0) {                                   // empty-target guard of compute_loss
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const long long idx = base + r * 64 + lane;
+            const long long idx = first[r] + lane;
             if (idx < n) out[idx] = -1;
         }
         if (want_restore && lane == 0) ws.wave_cnt[wslot] = 0;
@@ -206,7 +249,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         if (64 + lane < M) gB = gt[m0 + 64 + lane];
     }
     WaveTile t;
-    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, first, n);
     unsigned long long maskA = 0ull, maskB = 0ull;
     if (M <= RESIDENT) {
         maskA = __ballot(lane < M && overlaps_tile(t, gA));
@@ -266,7 +309,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
 
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long long idx = base + r * 64 + lane;
+        const long long idx = first[r] + lane;
         if (idx < n) {
             out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
             if (want_restore) put_argmax(ws, (long long)b * n + idx, bidx[r]);
@@ -287,7 +330,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
 // atomics and merged into the global maxima once per tile (images with more than GMAX_LDS GT keep the
 // per-chunk global atomics).
 __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void match_heavy_kernel(
-    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles,
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
     const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
     float high, float low, long long* __restrict__ matched) {
     constexpr int NW = HT / 64;
@@ -335,10 +378,11 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
         const int4 qi = ws.heavy_queue[(long long)b * wtiles + pick];
         const int wt = qi.x;
         const long long wslot = (long long)b * wtiles + wt;
-        const long long base = (long long)wt * WTILE;
+        long long first[R];
+        tile_runs(layout, wt, first);
         long long* out = matched + (long long)b * n;
         WaveTile t;
-        load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+        load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, first, n);
         float best[R];
         int bidx[R];
 #pragma unroll
@@ -395,16 +439,19 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
                 }
             }
         }
-        if (threadIdx.x < WTILE) {
-            float bb = s_best[0][threadIdx.x];
-            int bi = s_bidx[0][threadIdx.x];
+        for (int e = threadIdx.x; e < WTILE; e += HT) {  // anchor e & 63 of run e >> 6
+            float bb = s_best[0][e];
+            int bi = s_bidx[0][e];
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
-                const float ob = s_best[w][threadIdx.x];
-                const int oi = s_bidx[w][threadIdx.x];
+                const float ob = s_best[w][e];
+                const int oi = s_bidx[w][e];
                 if (ob > bb || (ob == bb && oi < bi)) { bb = ob; bi = oi; }
             }
-            const long long idx = base + threadIdx.x;
+            long long run = first[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) run = ((e >> 6) == r) ? first[r] : run;
+            const long long idx = run + (e & 63);
             if (idx < n) {
                 out[idx] = (bb < low) ? -1 : ((bb < high) ? -2 : (long long)bi);
                 if (want_restore) put_argmax(ws, (long long)b * n + idx, bi);
@@ -426,17 +473,19 @@ __global__ __launch_bounds__(256) void match_init_kernel(MatchWs ws, long long m
 // are recomputed with the same code as in the assign kernel (bit-identical values) and every anchor that
 // attains a GT's global maximum is restored.  All 64 lanes must call it with wave-uniform arguments.
 __device__ __forceinline__ void recheck_segment(const float4* __restrict__ anchors, long long anchor_batch_stride,
-                                                long long n, int wtiles, const float4* __restrict__ gt,
+                                                long long n, int wtiles, const TileLayout& layout,
+                                                const float4* __restrict__ gt,
                                                 const int* __restrict__ gt_offsets, const MatchWs& ws, int wslot,
                                                 int g_begin, int g_count, long long* __restrict__ matched) {
     const int lane = threadIdx.x & 63;
     const int b = wslot / wtiles, wt = wslot - b * wtiles;
-    const long long base = (long long)wt * WTILE;
+    long long first[R];
+    tile_runs(layout, wt, first);
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     if (g_begin >= M) return;
     WaveTile t;
-    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, base, n);
+    load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, first, n);
     bool restore[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) restore[r] = false;
@@ -454,7 +503,7 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
         [&](int, uint32_t) {});
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long long idx = base + r * 64 + lane;
+        const long long idx = first[r] + lane;
         if (idx < n && restore[r]) matched[(long long)b * n + idx] = (long long)get_argmax(ws, (long long)b * n + idx);
     }
 }
@@ -463,33 +512,36 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
 // with the code of the assign kernels (bit-identical values) and restores every anchor that attains the maximum.
 // The loads of all RB segments are issued before the first IoU, so a wave with several hits (neighbouring tiles
 // often tie for the same GT) pays the memory latency once.  Wave-uniform arguments; wslot[q] < 0 = unused.
-constexpr int RB = 4;
+#ifndef OD_RB
+#define OD_RB 4
+#endif
+constexpr int RB = OD_RB;
 __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ anchors, long long anchor_batch_stride,
-                                                     long long n, int wtiles, const float4* __restrict__ gt,
+                                                     long long n, int wtiles, const TileLayout& layout,
+                                                     const float4* __restrict__ gt,
                                                      const int* __restrict__ gt_offsets, const MatchWs& ws,
                                                      const int (&wslot)[RB], const int (&g)[RB], const uint32_t (&key)[RB],
                                                      long long* __restrict__ matched) {
     const int lane = threadIdx.x & 63;
     float4 a[RB][R], gb[RB];
     int am[RB][R];                                         // the anchors' argmax, requested with the boxes
-    long long first[RB];                                   // flat index of the segment's first anchor in `matched`
-    long long left[RB];                                    // anchors of the image from the segment's start
+    long long first[RB][R];                                // first anchor of each run of the segment's tile
+    long long image0[RB];                                  // flat index of the image's first anchor in `matched`
 #pragma unroll
     for (int q = 0; q < RB; ++q) {
         if (wslot[q] < 0) continue;
         const int b = wslot[q] / wtiles, wt = wslot[q] - b * wtiles;
-        const long long base = (long long)wt * WTILE;
+        tile_runs(layout, wt, first[q]);
         const float4* A = anchors + (long long)b * anchor_batch_stride;
         // g[q] indexes the batch's GT list; a vector load, so that the wave does not stop for a scalar one before
         // the anchor loads of the next segment are issued
         int gi = g[q];
         asm volatile("" : "+v"(gi));
         gb[q] = gt[gi];
-        first[q] = (long long)b * n + base;
-        left[q] = n - base;
+        image0[q] = (long long)b * n;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const long long idx = base + r * 64 + lane;
+            const long long idx = first[q][r] + lane;
             const long long ic = idx < n ? idx : n - 1;
             a[q][r] = A[ic];
             am[q][r] = get_argmax(ws, (long long)b * n + ic);
@@ -504,8 +556,8 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
             const float4 v4 = a[q][r];
             const float v = iou_pair(gb[q].x, gb[q].y, gb[q].z, gb[q].w, ga, v4.x, v4.y, v4.z, v4.w,
                                      box_area(v4.x, v4.y, v4.z, v4.w));
-            const long long off = r * 64 + lane;
-            if (off < left[q] && ordered_key(v) == key[q]) matched[first[q] + off] = (long long)am[q][r];
+            const long long idx = first[q][r] + lane;
+            if (idx < n && ordered_key(v) == key[q]) matched[image0[q] + idx] = (long long)am[q][r];
         }
     }
 }
@@ -519,9 +571,9 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
 // anchor); the values written are the ones the entry blocks write, so the order between the blocks is irrelevant.
 constexpr int ZB = 8;
 __global__ __launch_bounds__(256) void match_restore_kernel(
-    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int batch,
-    int light_blocks, int heavy_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
-    long long* __restrict__ matched) {
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
+    int batch, int light_blocks, int heavy_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets,
+    MatchWs ws, long long* __restrict__ matched) {
     const long long total = (long long)batch * wtiles;
     const int lane = threadIdx.x & 63;
     const bool light = (int)blockIdx.x < light_blocks;
@@ -595,7 +647,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
                     hk[q] = (uint32_t)bcast_lane((int)key, src);
                 }
             }
-            restore_row_segments(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, hs, hg, hk, matched);
+            restore_row_segments(anchors, anchor_batch_stride, n, wtiles, layout, gt, gt_offsets, ws, hs, hg, hk, matched);
         }
     }
     if (overflow && hb / batch < hblocks) {   // one wave per (heavy tile, 64-GT chunk)
@@ -604,7 +656,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
         for (long long q = first >> 6; q < items; q += nthreads >> 6) {
             const long long h = q / chunks;
             const int wslot = hb_image * wtiles + ws.heavy_queue[(long long)hb_image * wtiles + h].x;
-            recheck_segment(anchors, anchor_batch_stride, n, wtiles, gt, gt_offsets, ws, wslot, (int)(q - h * chunks) * 64,
+            recheck_segment(anchors, anchor_batch_stride, n, wtiles, layout, gt, gt_offsets, ws, wslot, (int)(q - h * chunks) * 64,
                             64, matched);
         }
     }
@@ -807,7 +859,37 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
                                   const float* gt_boxes, const int32_t* gt_offsets, int64_t m_total,
                                   int32_t batch, float high, float low, int32_t allow_low_quality,
                                   int64_t* matched, void* workspace, size_t workspace_bytes, void* stream) {
-    if (n < 0 || batch < 0 || m_total < 0) return OD_ERR_ARG;
+    return od_match_retinanet_grids(anchors, anchor_batch_stride, n, nullptr, 0, gt_boxes, gt_offsets, m_total, batch, high,
+                                    low, allow_low_quality, matched, workspace, workspace_bytes, stream);
+}
+
+extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_batch_stride, int64_t n,
+                                        const int64_t* anchor_grids, int32_t num_grids,
+                                        const float* gt_boxes, const int32_t* gt_offsets, int64_t m_total,
+                                        int32_t batch, float high, float low, int32_t allow_low_quality,
+                                        int64_t* matched, void* workspace, size_t workspace_bytes, void* stream) {
+    if (n < 0 || batch < 0 || m_total < 0 || num_grids < 0 || (num_grids > 0 && !anchor_grids)) return OD_ERR_ARG;
+    // A grid the tiles cannot follow (see TileLayout) is simply not used; grids must lie inside [0, n), ascending and
+    // disjoint, else the argument is wrong.
+    TileLayout layout;
+    memset(&layout, 0, sizeof(layout));
+    {
+        int64_t prev_end = 0;
+        for (int32_t i = 0; i < num_grids; ++i) {
+            const int64_t first = anchor_grids[3 * i], row_len = anchor_grids[3 * i + 1], rows = anchor_grids[3 * i + 2];
+            if (first < prev_end || row_len <= 0 || rows <= 0 || row_len > 0x7fffffffll || rows > 0x7fffffffll) return OD_ERR_ARG;
+            if (row_len * rows > n - first) return OD_ERR_ARG;
+            prev_end = first + row_len * rows;
+            if (first % WTILE != 0 || row_len % 64 != 0 || rows % R != 0) continue;
+            if (prev_end / WTILE > 0xffffff || layout.grids == MAX_GRIDS) continue;
+            const int k = layout.grids++;
+            layout.tile_begin[k] = (int)(first / WTILE);
+            layout.tile_end[k] = (int)(prev_end / WTILE);
+            layout.runs[k] = (int)(row_len / 64);
+            layout.inv_runs[k] = 1.0f / (float)layout.runs[k];
+            layout.row_len[k] = (int)row_len;
+        }
+    }
     if (n == 0 || batch == 0) return OD_OK;
     if (!anchors || !gt_offsets || !matched || (m_total > 0 && !gt_boxes)) return OD_ERR_ARG;
     if (anchor_batch_stride != 0 && anchor_batch_stride < n) return OD_ERR_ARG;
@@ -841,13 +923,13 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
     }
     const long long stride = (long long)anchor_batch_stride;
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
-                     (long long)n, wtiles, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
+                     (long long)n, wtiles, layout, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
                      (long long*)matched);
     if (m_total > HEAVY) {
         int heavy_y = 4096 / batch > 64 ? 4096 / batch : 64;
         if (heavy_y > wtiles) heavy_y = wtiles;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_HEAVY, match_heavy_kernel, dim3((unsigned)batch, (unsigned)heavy_y),
-                         dim3(HT), 0, s, (const float4*)anchors, stride, (long long)n, wtiles,
+                         dim3(HT), 0, s, (const float4*)anchors, stride, (long long)n, wtiles, layout,
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
@@ -856,7 +938,7 @@ extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_str
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
                          dim3((unsigned)(light_blocks + heavy_entry_blocks + batch * ZB)), dim3(256), 0, s,
-                         (const float4*)anchors, stride, (long long)n, wtiles, (int)batch, light_blocks,
+                         (const float4*)anchors, stride, (long long)n, wtiles, layout, (int)batch, light_blocks,
                          heavy_entry_blocks, (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
     }
     return OD_OK;

@@ -104,6 +104,9 @@ def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
 
 
 # ------------------------------------------------------------------------------------------------
+_grid_tables: Dict[tuple, "ctypes.Array"] = {}     # host tables of anchor grids, kept alive per geometry
+
+
 def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tuple[int, int]],
                     cell_anchors: Sequence[Tensor], device: torch.device) -> Tensor:
     """All pyramid anchors, [N,4] fp32 on ``device``, order (level, y, x, a)."""
@@ -120,7 +123,11 @@ def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tup
     rc = _C.lib().od_anchor_generate(gh, gw, sh, sw, nb, ctypes.c_void_p(base.data_ptr()), L, _ptr(out), n_total,
                                      _stream(device))
     _C.check(rc, "od_anchor_generate")
-    return out
+    firsts, first = [], 0
+    for g, c in zip(grid_sizes, cell_anchors):
+        firsts.append((first, int(g[1]) * int(c.shape[0]), int(g[0])))
+        first += int(g[0]) * int(g[1]) * int(c.shape[0])
+    return set_anchor_grids(out, firsts)
 
 
 def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, Tensor, int]:
@@ -140,11 +147,22 @@ def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, T
     return gt, _device_ints(offsets, device), m_total
 
 
+def set_anchor_grids(anchors: Tensor, grids: Sequence[Tuple[int, int, int]]) -> Tensor:
+    """Note on an anchor tensor how its list is ordered: ``(first, row_len, rows)`` per pyramid level (anchors
+    [first, first + row_len * rows) are ``rows`` grid rows of ``row_len`` anchors).  ``match_retinanet`` passes the
+    note to the matching kernels, which use it to form tighter tiles; results do not depend on it."""
+    anchors._od_anchor_grids = tuple((int(f), int(l), int(r)) for f, l, r in grids)
+    return anchors
+
+
 def match_retinanet(anchors: Tensor, gt_list: Sequence[Tensor], high: float, low: float,
-                    allow_low_quality: bool = True) -> Tensor:
-    """Fused box_iou + Matcher.  anchors [N,4] (shared) or [B,N,4]; returns int64 [B,N]."""
+                    allow_low_quality: bool = True, grids: Optional[Sequence[Tuple[int, int, int]]] = None) -> Tensor:
+    """Fused box_iou + Matcher.  anchors [N,4] (shared) or [B,N,4]; returns int64 [B,N].  ``grids``: see
+    ``set_anchor_grids`` (default: the note on the tensor, if any)."""
     _require_gpu(anchors, "anchors")
     dev = anchors.device
+    if grids is None:
+        grids = getattr(anchors, "_od_anchor_grids", None)
     anchors = _f32c(anchors)
     B = len(gt_list)
     if anchors.dim() == 3:
@@ -159,9 +177,18 @@ def match_retinanet(anchors: Tensor, gt_list: Sequence[Tensor], high: float, low
     if nbytes is None:
         nbytes = _ws_bytes[("match", m_total, B, n)] = lib.od_match_retinanet_workspace_bytes(m_total, B, n)
     ws = _workspace(dev, "match", nbytes)
-    rc = lib.od_match_retinanet(_ptr(anchors), stride, n, _ptr(gt), _ptr(offsets), m_total, B, float(high),
-                                float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws), ws.numel(),
-                                _stream(dev))
+    if grids:
+        key = tuple(grids)
+        table = _grid_tables.get(key)
+        if table is None:
+            table = _grid_tables[key] = (ctypes.c_int64 * (3 * len(key)))(*[int(v) for g in key for v in g])
+        rc = lib.od_match_retinanet_grids(_ptr(anchors), stride, n, table, len(key), _ptr(gt), _ptr(offsets), m_total, B,
+                                          float(high), float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws),
+                                          ws.numel(), _stream(dev))
+    else:
+        rc = lib.od_match_retinanet(_ptr(anchors), stride, n, _ptr(gt), _ptr(offsets), m_total, B, float(high),
+                                    float(low), int(bool(allow_low_quality)), _ptr(matched), _ptr(ws), ws.numel(),
+                                    _stream(dev))
     _C.check(rc, "od_match_retinanet")
     return matched
 

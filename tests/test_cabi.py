@@ -60,6 +60,11 @@ def test_argument_errors_without_gpu():
     assert lib.od_anchor_generate(null, null, null, null, null, null, 1, null, 0, null) == -1
     assert lib.od_anchor_generate(i32, i32, i32, i32, i32, (ctypes.c_float * 64)(), 9, ctypes.c_void_p(16), 0, null) == -2
     assert lib.od_match_retinanet(null, 0, 10, null, null, 0, 1, 0.6, 0.5, 1, null, null, 0, null) == -1
+    import ctypes as ct
+    bad = (ct.c_int64 * 6)(0, 64, 4, 128, 64, 4)                     # second grid starts inside the first
+    assert lib.od_match_retinanet_grids(null, 0, 1024, bad, 2, null, null, 0, 1, 0.6, 0.5, 1, null, null, 0, null) == -1
+    beyond = (ct.c_int64 * 3)(512, 64, 16)                           # reaches past the last anchor
+    assert lib.od_match_retinanet_grids(null, 0, 1024, beyond, 1, null, null, 0, 1, 0.6, 0.5, 1, null, null, 0, null) == -1
     assert lib.od_matcher(null, 0, 5, 0.6, 0.5, 1, null, null, 0, null) == -1
     assert lib.od_batched_nms(null, null, null, null, 1, 10, 0, 1, 0.5, 0, 10, null, null, null, null, null, null, 0, null) == -1
     assert lib.od_batched_nms(ctypes.c_void_p(16), ctypes.c_void_p(16), null, ctypes.c_void_p(16), 1, 70000, 0, 1, 0.5, 0,

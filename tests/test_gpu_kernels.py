@@ -50,6 +50,47 @@ def test_match_retinanet(device, m):
     assert np.array_equal(out_nolq[0].numpy(), c_oracle.match_retinanet(gts[0].numpy(), anchors.numpy(), 0.6, 0.5, False))
 
 
+def _grids_of(grids, per_location):
+    """(first, row_len, rows) of every level of square pyramid grids with `per_location` anchors per cell."""
+    out, first = [], 0
+    for g in grids:
+        out.append((first, g * per_location, g))
+        first += g * g * per_location
+    return out
+
+
+@pytest.mark.parametrize("m", [7, 100, 700])
+def test_match_retinanet_anchor_grids(device, m):
+    """The hint about the order of the anchor list (od_match_retinanet_grids) changes which anchors share a tile and
+    nothing else: same matches as the scalar checker and as the call without the hint -- on a pyramid whose first
+    level the tiles can follow and whose other levels they cannot (9 anchors per cell), on one where every level
+    qualifies (1 anchor per cell), with an anchor count that is not a multiple of the tile size, with a table per
+    image, with GT that overlap nothing, with an image without GT."""
+    cases = [((512, 512), (64, 32, 16, 8, 4), synthetic.retinanet_anchor_sizes(5, 32), (0.5, 1.0, 2.0)),
+             ((512, 512), (128, 64, 5), ((16,), (32,), (64,)), (1.0,))]
+    for image, grids, sizes, ratios in cases:
+        ag, anchors = _anchors_cpu(image, grids, sizes, ratios)
+        hint = _grids_of(grids, len(sizes[0]) * len(ratios))
+        assert hint[-1][0] + hint[-1][1] * hint[-1][2] == anchors.shape[0]
+        gts = [synthetic.make_gt_boxes(m if b != 1 else m - 1, image, torch.Generator().manual_seed(31 * m + b)) for b in range(3)]
+        gts[2] = torch.cat((gts[2][:3], torch.tensor([[9000., 9000., 9010., 9020.]]), gts[2][3:]))   # restores every anchor
+        gts.append(torch.zeros((0, 4)))
+        g_d = [g.to(device) for g in gts]
+        for lq in (True, False):
+            plain = kernels.match_retinanet(anchors.to(device), g_d, 0.6, 0.5, lq, grids=()).cpu()
+            hinted = kernels.match_retinanet(anchors.to(device), g_d, 0.6, 0.5, lq, grids=hint).cpu()
+            assert torch.equal(plain, hinted), (grids, lq)
+            for b, g in enumerate(gts):
+                assert np.array_equal(hinted[b].numpy(), c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, lq)), (grids, lq, b)
+        tables = torch.stack([anchors * (1.0 + 0.05 * b) + 2.0 * b for b in range(len(gts))])
+        out = kernels.match_retinanet(tables.to(device), g_d, 0.6, 0.5, True, grids=hint).cpu()
+        for b, g in enumerate(gts):
+            assert np.array_equal(out[b].numpy(), c_oracle.match_retinanet(g.numpy(), tables[b].numpy(), 0.6, 0.5, True)), (grids, b)
+    # the anchor generator leaves the note on its output, and the matching picks it up
+    gen = kernels.anchor_generate([(64, 64), (32, 32)], [(8, 8), (16, 16)], ag.cell_anchors[:2], device)
+    assert gen._od_anchor_grids == ((0, 64, 64), (4096, 32, 32))
+
+
 def test_batched_anchor_tables(device):
     """Anchors given per image ([B, N, 4], anchor_batch_stride = N) instead of one table shared by the batch:
     od_match_retinanet, od_match_fcos and od_select_candidates against the scalar checker, image by image."""
