@@ -88,7 +88,7 @@ __device__ __forceinline__ long long entry_cap(int M) { return (long long)HCAP_P
 // the anchor list is a grid (`rows` rows of `row_len` anchors, neighbouring rows spatially adjacent: a pyramid level in
 // (y, x, a) order) and the range fits (start a multiple of 256, row_len a multiple of 64, rows a multiple of R), a tile
 // is R rows x 64 anchors instead: R runs of 64 consecutive anchors, one below the other.  Its bounding box is a
-// fraction as wide, so it meets fewer GT (finest level of a 1024 x 1024 image: 2.2 -> 1.3 GT per tile), and the loads
+// fraction as wide, so it meets fewer GT (finest level of a 1024 x 1024 image: 2.2 -> 1.5 GT per tile), and the loads
 // and stores stay 1 KiB / 512 B runs.  Any assignment of anchors to tiles gives the same results; the tile numbers
 // [0, wtiles) and the number of anchors per tile do not change.
 constexpr int MAX_GRIDS = 8;
