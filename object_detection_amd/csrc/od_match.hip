@@ -174,7 +174,9 @@ __device__ __forceinline__ void visit_survivors(unsigned long long mask, const f
 template <typename F, typename D>
 __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const float4* __restrict__ gt, int m0,
                                                         const uint32_t* gmax, int g_begin, int g_end, int share,
-                                                        int nshare, F f, D chunk_done) {
+                                                        int nshare, F f, D chunk_done, int chunk_step = 1) {
+    // chunk_step > 1: only every chunk_step-th 64-GT chunk, starting with the one at g_begin (waves that split a long
+    // GT list by chunks instead of by rank do not repeat each other's culling)
     const int lane = threadIdx.x & 63;
     float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
     uint32_t nxt_max = 0u;
@@ -183,10 +185,10 @@ __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const
         if (gmax) nxt_max = gmax[(long long)(m0 + g_begin + lane) * GSTRIDE];
     }
     int rank = 0;
-    for (int g0 = g_begin; g0 < g_end; g0 += 64) {
+    for (int g0 = g_begin; g0 < g_end; g0 += 64 * chunk_step) {
         const float4 gb = nxt;
         const uint32_t cur = nxt_max;
-        const int gn = g0 + 64 + lane;
+        const int gn = g0 + 64 * chunk_step + lane;
         if (gn < g_end) {                              // prefetch the next chunk
             nxt = gt[m0 + gn];
             if (gmax) nxt_max = gmax[(long long)(m0 + gn) * GSTRIDE];
@@ -407,7 +409,12 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
             }
             staged = 0;
         };
-        for_each_overlapping_gt(t, gt, m0, (want_restore && !lds_max) ? ws.gt_max_key : nullptr, 0, M, wave, NW,
+        // Short GT lists: every wave culls all GT and takes every NW-th survivor (even split whatever the list looks
+        // like).  Long lists: every wave takes every NW-th chunk of 64 GT, culling included -- with 2000 GT the
+        // culling of all chunks by all waves was 40 % of the kernel's instructions.
+        const bool by_chunk = M > 64 * NW * 2;
+        for_each_overlapping_gt(t, gt, m0, (want_restore && !lds_max) ? ws.gt_max_key : nullptr, by_chunk ? 64 * wave : 0, M,
+                                by_chunk ? 0 : wave, by_chunk ? 1 : NW,
             [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
                 const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
                 if (want_restore && k > kZeroKey) {    // wave-uniform: this GT overlaps an anchor of the tile
@@ -424,7 +431,7 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
                     atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
                 }
                 kreg = 0u;
-            });
+            }, by_chunk ? NW : 1);
         flush_entries();
 #pragma unroll
         for (int r = 0; r < R; ++r) { s_best[wave][r * 64 + lane] = best[r]; s_bidx[wave][r * 64 + lane] = bidx[r]; }
