@@ -519,8 +519,10 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
 // with the code of the assign kernels (bit-identical values) and restores every anchor that attains the maximum.
 // The loads of all RB segments are issued before the first IoU, so a wave with several hits (neighbouring tiles
 // often tie for the same GT) pays the memory latency once.  Wave-uniform arguments; wslot[q] < 0 = unused.
+// RB = 1 measured best (restore 19.5 / 18.2 / 17.1 us for RB = 4 / 2 / 1): the registers of further segments (138 / 82 /
+// 60 VGPRs) cost more occupancy in this latency-bound kernel than the shared round trip saves.
 #ifndef OD_RB
-#define OD_RB 4
+#define OD_RB 1
 #endif
 constexpr int RB = OD_RB;
 __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ anchors, long long anchor_batch_stride,
@@ -616,21 +618,31 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     }
     // Heavy entries: consecutive entries belong to one tile and often hit together, so they are dealt to different
     // waves (entry = lane * waves + wave); light entries are slot-major already.
+    // A light block takes 256 neighbouring tiles at one entry slot (block -> slot and tile range by a scalar division,
+    // nothing per thread): items = LCAP * tile_blocks, dealt to the light blocks in turn.
     const long long nwaves = nthreads >> 6, wave_id = first >> 6;
-    for (long long k0 = 0; k0 < limit; k0 += nthreads) {
-        const long long i = light ? k0 + first + lane : k0 + (long long)lane * nwaves + wave_id;
+    const long long tile_blocks = (total + 255) >> 8;
+    const long long light_items = tile_blocks * LCAP;
+    for (long long k0 = 0; light ? (k0 + blockIdx.x < light_items) : (k0 < limit); k0 += light ? (long long)light_blocks : nthreads) {
         uint32_t word = 0u, key = 0u;
         int wslot = 0;
         bool have = false;
-        if (i < limit) {
-            if (light) {                                 // slot-major: neighbouring threads, neighbouring tiles
-                const int e = (int)(i / total);
-                wslot = (int)(i - (long long)e * total);
+        if (light) {                                     // slot-major: neighbouring threads, neighbouring tiles
+            const uint32_t item = (uint32_t)(k0 + blockIdx.x);          // < LCAP * 2^23: 32-bit division
+            const int e = (int)(item / (uint32_t)tile_blocks);
+            const long long tile = (long long)(item - (uint32_t)e * (uint32_t)tile_blocks) * 256 + threadIdx.x;
+            if (tile < total) {
+                wslot = (int)tile;
+                // the slot is read together with the tile's entry count (one memory round trip instead of two); a
+                // slot beyond the count holds stale data and is ignored
+                const uint2 ent = ws.wave_list[(long long)e * total + tile];
                 if (e < ws.wave_cnt[wslot]) {            // also skips heavy tiles (-2)
-                    const uint2 ent = ws.wave_list[i];
                     word = ent.x; key = ent.y; have = true;
                 }
-            } else {
+            }
+        } else {
+            const long long i = k0 + (long long)lane * nwaves + wave_id;
+            if (i < limit) {
                 const uint4 ent = ws.heavy_entries[ebase + i];
                 wslot = (int)ent.x; word = ent.y; key = ent.z; have = true;
             }
@@ -940,8 +952,8 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
-        const long long light_threads = total_tiles * LCAP;
-        const int light_blocks = (int)((light_threads + 255) / 256 < 8192 ? (light_threads + 255) / 256 : 8192);
+        const long long light_items = ((total_tiles + 255) / 256) * LCAP;       // (entry slot, 256 tiles)
+        const int light_blocks = (int)(light_items < 16384 ? light_items : 16384);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
                          dim3((unsigned)(light_blocks + heavy_entry_blocks + batch * ZB)), dim3(256), 0, s,

@@ -24,6 +24,8 @@ def pair_rates(pairs: float, us: float) -> dict:
 
 
 def main():
+    if os.environ.get("OD_LIB"):                       # experimental build of the library
+        _C.LIB_PATH = os.path.abspath(os.environ["OD_LIB"])
     dev = torch.device("cuda:0")
     res = {}
 
