@@ -14,7 +14,9 @@
 //     through a ballot mask and broadcast with v_readlane: no LDS, no barriers, scalar loop control,
 //     and "first maximal index" tie-breaking is unchanged.
 //   * a wave tile that meets more than HEAVY GT (coarse pyramid levels) would be a long serial loop on
-//     the critical path; it is queued and processed by 16 cooperating waves instead (heavy kernel).
+//     the critical path; it is queued and processed by 4 cooperating waves instead (heavy kernel).
+//   * which 256 anchors share a tile is a free choice: consecutive ones by default, 4 grid rows x 64 anchors where
+//     the caller describes the anchor list as grids (TileLayout), which makes the tiles' boxes tighter.
 //
 // assign / heavy kernels: per-anchor max / argmax / thresholds -> `matched`, the raw argmax -> workspace,
 //   per-GT maximum over the wave's anchors (DPP max) -> global atomic max, and one 8-byte entry per
