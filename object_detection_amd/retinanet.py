@@ -147,7 +147,7 @@ class _PendingBatch:
     """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into a row of
     pinned memory + an event recorded behind it).  ``counts()`` waits for that event once.  The pinned rows are handed
     out in turn; a row whose previous batch was never looked at is read out (one wait) before it is reused."""
-    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "members", "__weakref__")
+    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "__weakref__")
 
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
         self.boxes, self.scores, self.labels = boxes, scores, labels
@@ -168,7 +168,6 @@ class _PendingBatch:
         self.event.record()
         self._counts = None
         self._rows = None
-        self.members = ()                   # weak references to the Detections of the batch that are not filled yet
 
     def counts(self) -> List[int]:
         if self._counts is None:
@@ -196,6 +195,7 @@ class _ReadyDetections(dict):
     """What a ``Detections`` object becomes once its tensors are cut out: a plain dictionary again (no Python-level
     method between the caller and ``dict``), which keeps answering ``defer_box_scale`` with False."""
 
+    __slots__ = ("_pending", "_index", "_scale")             # the layout of Detections: the class is swapped in place
     __hash__ = None
 
     def defer_box_scale(self, scale: Tensor) -> bool:
@@ -205,15 +205,17 @@ class _ReadyDetections(dict):
 class Detections(dict):
     """``{"boxes": [d, 4], "scores": [d], "labels": [d]}`` of one image, as ``postprocess_detections`` returns it.  The
     number of detections d is only known on the GPU when the call returns; the three tensors are cut out of the padded
-    outputs of the batch at the first access to the dictionary of ANY image of the batch, which waits for the counts of
-    the batch (one event) and fills the dictionaries of all its images -- the call itself never makes the host wait
-    for the GPU.  A filled dictionary turns into a plain ``dict`` subclass without overridden accessors."""
+    outputs of the batch at the first access to the dictionary, which waits for the counts of the batch (one event;
+    the first access to any image of the batch also cuts the three padded tensors for all its images, three calls into
+    torch) -- the call itself never makes the host wait for the GPU.  A filled dictionary turns into a plain ``dict``
+    subclass without overridden accessors."""
+
+    __slots__ = ("_pending", "_index", "_scale")
 
     def __init__(self, pending: _PendingBatch, index: int):
-        super().__init__()
-        self._pending: Optional[_PendingBatch] = pending
+        self._pending = pending
         self._index = index
-        self._scale: Optional[Tensor] = None
+        self._scale = None
 
     def defer_box_scale(self, scale: Tensor) -> bool:
         """Multiply the boxes by ``scale`` [4] when they are cut out (the rescale of ``transform.postprocess``);
@@ -237,12 +239,8 @@ class Detections(dict):
         if p is None:
             return
         rb, rs, rl = p.rows()
-        for ref in p.members:                    # every image of the batch that is still alive, this one included
-            d = ref()
-            if d is not None:
-                i = d._index
-                d._fill(rb[i], rs[i], rl[i])
-        p.members = ()
+        i = self._index
+        self._fill(rb[i], rs[i], rl[i])
 
     def __getitem__(self, key):
         self._materialize()
@@ -336,9 +334,7 @@ def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thr
     if return_padded:
         return ob, os_, ol, oc
     pending = _PendingBatch(ob, os_, ol, oc)
-    out = [Detections(pending, i) for i in range(ob.shape[0])]
-    pending.members = [weakref.ref(d) for d in out]
-    return out
+    return [Detections(pending, i) for i in range(ob.shape[0])]
 
 
 class RetinaNet(nn.Module):
