@@ -294,25 +294,26 @@ def main():
     # own.  Graphs of consecutive steps are replayed on two launch streams in turn, so that the narrow tail of one
     # step (top-k, NMS) runs beside the chip-wide kernels of the next.  Every graph was recorded on streams of its own
     # and therefore owns its scratch buffers; a graph is always replayed on the same launch stream.
-    launch_streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-    graphs, accumulators = [], []
+    launch_streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    graphs_post, graphs_match, accumulators = [], [], []
 
     def record_graphs():
+        # Two graphs per resident batch, the inference half and the matching half: replayed on different streams they
+        # overlap like the eager launches do.  (One graph holding both halves as parallel branches was measured
+        # slower than the eager issue: its branches did not run side by side.)
         for r in range(n_rot):
-            side = torch.cuda.Stream(dev)
             acc = torch.zeros((cfg.batch,), dtype=torch.int32, device=dev)     # detections of all replays, per image
 
-            def recorded(r=r, side=side, acc=acc):
-                main = torch.cuda.current_stream(dev)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    matched = model.match_anchors(batches[r][1], anchors_per_image)
+            def recorded_post(r=r, acc=acc):
                 ob, os_, ol, oc = post_padded(r)
                 acc.add_(oc)
-                main.wait_stream(side)
-                return ob, os_, ol, oc, matched
+                return ob, os_, ol, oc
 
-            graphs.append(graph_step.capture(recorded, dev, warmup=2, side_streams=[side]))
+            def recorded_match(r=r):
+                return model.match_anchors(batches[r][1], anchors_per_image)
+
+            graphs_post.append(graph_step.capture(recorded_post, dev, warmup=2))
+            graphs_match.append(graph_step.capture(recorded_match, dev, warmup=2))
             accumulators.append(acc)
         torch.cuda.synchronize(dev)
         for acc in accumulators:
@@ -324,9 +325,11 @@ def main():
     def graph_step_run(i):
         r = i % n_rot
         torch.cuda.set_stream(launch_streams[r & 1])
-        ob, os_, ol, oc, matched = graphs[r].replay()
+        ob, os_, ol, oc = graphs_post[r].replay()
         if world > 1:
             sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
+        torch.cuda.set_stream(launch_streams[2])
+        matched = graphs_match[r].replay()
         return matched, oc
 
     step = graph_step_run if use_graph else eager_step
@@ -475,7 +478,7 @@ def main():
         ms_post = timed_loop(lambda i: post_padded(i % n_rot), 20)
         ms_match = timed_loop(lambda i: model.match_anchors(batches[i % n_rot][1], anchors_per_image), 20)
         if not use_graph and world == 1:
-            # the recorded form of the step (one HIP graph per resident batch, replayed on two launch streams in turn)
+            # the recorded form of the step (two HIP graphs per resident batch, replayed on three launch streams)
             record_graphs()
             ms_graph = timed_loop(graph_step_run, min(args.steps, 100))
 
@@ -508,7 +511,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
-            "step_launch": "one recorded HIP graph per step" if use_graph else "every kernel launched from the host",
+            "step_launch": "two recorded HIP graphs per step (inference half, matching half)" if use_graph else "every kernel launched from the host",
             "ms_per_step_host_enqueue": 1e3 * host_enqueue / args.steps,
             "ms_per_step_eager_with_timed_kernel": ms_timed_kernel,
             "ms_per_step_graph_replay": ms_graph,
