@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--rotate", type=int, default=4,
                     help="resident input batches used in rotation by consecutive steps (4 x 403 MB of head outputs: "
                          "several times the 256 MiB last-level cache); rounded up to an even number")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="N > 1: the padded detections of this many consecutive steps of a stream travel in one "
+                         "all-gather (1 = an exchange in every step); what is left is exchanged before the clock stops")
     ap.add_argument("--graph", action="store_true",
                     help="timed region: replay the step's recorded HIP graph instead of launching every kernel from the "
                          "host (measured slower on this runtime; without the flag the replay rate is a secondary figure)")
@@ -268,6 +271,22 @@ def main():
     for st in s_posts + s_matches:
         st.wait_stream(default_stream)
 
+    # N > 1: one ring of message buffers per stream that runs inference halves (sharding.DetectionGatherRing)
+    rings = {}
+
+    def exchange(ob, os_, ol, oc):
+        st = torch.cuda.current_stream(dev)
+        ring = rings.get(st.cuda_stream)
+        if ring is None:
+            ring = rings[st.cuda_stream] = (st, sharding.DetectionGatherRing(cfg.batch, cfg.detections_per_img,
+                                                                             args.gather_every, dev))
+        ring[1].add(ob, os_, ol, oc)
+
+    def flush_exchanges():
+        for st, ring in rings.values():                    # same order and fill level on every rank
+            torch.cuda.set_stream(st)
+            ring.flush()
+
     def eager_step(i=0, mode="padded", single_stream=False):
         """mode "padded": padded outputs, counts copied to pinned memory asynchronously; "api": the model's own
         postprocess_detections (per-image dictionaries, cut to size when first looked at); "api-blocking": the same,
@@ -279,7 +298,7 @@ def main():
         if mode == "padded":
             ob, os_, ol, oc = post_padded(r)
             if world > 1:
-                sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
+                exchange(ob, os_, ol, oc)
             count_rows[i % len(count_rows)].copy_(oc, non_blocking=True)
             out = oc
         else:
@@ -327,7 +346,7 @@ def main():
         torch.cuda.set_stream(launch_streams[r & 1])
         ob, os_, ol, oc = graphs_post[r].replay()
         if world > 1:
-            sharding.gather_padded_detections(ob, os_, ol, oc, reuse_buffers=True)
+            exchange(ob, os_, ol, oc)
         torch.cuda.set_stream(launch_streams[2])
         matched = graphs_match[r].replay()
         return matched, oc
@@ -335,6 +354,8 @@ def main():
     step = graph_step_run if use_graph else eager_step
 
     def sync():
+        if world > 1:
+            flush_exchanges()                              # detections still waiting in a ring travel now
         torch.cuda.set_stream(default_stream)
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -546,8 +567,8 @@ def main():
                 "logits": "synthetic 'stress' distribution N(-3, 1.5) + 0.1% saturated: 2.3% of the logits pass "
                           "score_thresh, every level overflows topk_candidates",
                 "parallelism": f"image-sharded x{world}" + (
-                    (", all-gather of detections (" + ("gloo over host memory: rehearsal on one GPU" if rehearsal
-                                                       else "RCCL") + ")") if world > 1 else ""),
+                    (f", all-gather of the padded detections of {args.gather_every} steps at a time (" +
+                     ("gloo over host memory: rehearsal on one GPU" if rehearsal else "RCCL") + ")") if world > 1 else ""),
                 "resident_batches_in_rotation": n_rot,
                 "hip_streams_eager": args.streams,
             },

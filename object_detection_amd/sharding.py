@@ -105,3 +105,49 @@ def gather_padded_detections(boxes: Tensor, scores: Tensor, labels: Tensor, coun
     local = kernels.pack_detections(boxes, scores, labels, counts, out=bufs[0])
     gathered = _exchange(local, bufs[1], group) if world > 1 else local
     return gathered[:, :-1].reshape(gathered.shape[0], D, 6), gathered[:, -1]
+
+
+class DetectionGatherRing:
+    """The same exchange, every ``period`` steps instead of every step: the padded detections of ``period`` consecutive
+    steps are packed into the rows of one message buffer (``od_pack_detections`` writes each step's rows in place) and
+    travel in ONE all-gather.  A collective call costs the host tens of microseconds and the GPU a latency-bound
+    kernel, whatever the message size below a few MB; an evaluation loop only needs every rank's detections when the
+    metric is computed (the reference accumulates predictions over the whole validation set,
+    ``object_detection/train.py:84-87``), so nothing waits for the individual steps.
+
+    ``add`` returns None until the buffer is full and then what ``flush`` returns: ``(packed [R, steps, B_local, D, 6]
+    fp32, counts [R, steps, B_local] fp32)`` over the R ranks, views of a buffer that the next round overwrites.
+    Call ``flush`` after the last step.  All calls of one ring must be made on the same stream."""
+
+    def __init__(self, batch: int, detections: int, period: int, device: torch.device, group=None):
+        self.B, self.D, self.period, self.group = int(batch), int(detections), max(1, int(period)), group
+        self.world = dist.get_world_size(group) if _distributed(group) else 1
+        width = 6 * self.D + 1
+        self.local = torch.empty((self.period, self.B, width), dtype=torch.float32, device=device)
+        self.gathered = (torch.empty((self.world * self.period * self.B, width), dtype=torch.float32, device=device)
+                         if self.world > 1 else None)
+        self.fill = 0
+
+    def add(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tensor):
+        row = self.local[self.fill]
+        if boxes.is_cuda:
+            from . import kernels
+            kernels.pack_detections(boxes, scores, labels, counts, out=row)
+        else:
+            row[:, :-1] = pack_detections(boxes, scores, labels).reshape(self.B, -1)
+            row[:, -1] = counts.to(torch.float32)
+        self.fill += 1
+        return self.flush() if self.fill == self.period else None
+
+    def flush(self):
+        steps, self.fill = self.fill, 0
+        if steps == 0:
+            return None
+        local = self.local[:steps].reshape(steps * self.B, -1)
+        if self.world > 1:
+            out = self.gathered[: self.world * steps * self.B] if self.gathered is not None else None
+            gathered = _exchange(local, out, self.group)
+        else:
+            gathered = local
+        g = gathered.reshape(self.world, steps, self.B, 6 * self.D + 1)
+        return g[..., :-1].reshape(self.world, steps, self.B, self.D, 6), g[..., -1]

@@ -40,6 +40,35 @@ def _worker(rank, world, port, total, d, ret):
     ok = ok and torch.equal(p2, full) and torch.equal(c2.to(torch.int32), counts)
     dets2 = sharding.unpack_detections(p2, c2)
     ok = ok and all(torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["labels"], b["labels"]) for a, b in zip(dets, dets2))
+    # the exchange every few steps: 7 steps through a ring of 3 (two full rounds and a flush of one step) give, step by
+    # step, what the per-step exchange gives
+    steps = 7
+    data = []
+    for t in range(steps):
+        g2 = torch.Generator().manual_seed(100 + t)
+        data.append((torch.rand((total, d, 4), generator=g2), torch.rand((total, d), generator=g2),
+                     torch.randint(0, 91, (total, d), generator=g2), torch.randint(0, d + 1, (total,), generator=g2, dtype=torch.int32)))
+    ring = sharding.DetectionGatherRing(hi - lo, d, 3, torch.device("cpu"))
+    seen = []
+    for t in range(steps):
+        bx, sc, lb, ct = data[t]
+        out = ring.add(bx[lo:hi], sc[lo:hi], lb[lo:hi], ct[lo:hi])
+        ok = ok and ((out is not None) == (t % 3 == 2))
+        if out is not None:
+            seen.append((out[0].clone(), out[1].clone()))      # views of the ring's buffer: the next round overwrites them
+    out = ring.flush()
+    ok = ok and out is not None and ring.flush() is None
+    seen.append(out)
+    t = 0
+    for g_p, g_c in seen:
+        ok = ok and g_p.shape[0] == world and g_p.shape[2] == hi - lo
+        for k in range(g_p.shape[1]):
+            bx, sc, lb, ct = data[t]
+            step_packed = g_p[:, k].reshape(total, d, 6)        # rank order = image order (equal shards)
+            ok = ok and torch.equal(step_packed, sharding.pack_detections(bx, sc, lb))
+            ok = ok and torch.equal(g_c[:, k].reshape(total).to(torch.int32), ct)
+            t += 1
+    ok = ok and t == steps
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -86,6 +115,19 @@ def _gpu_worker(rank, world, port, ret):
     ok = ok and all(torch.equal(d["boxes"], fb[i, :int(fc[i])]) and torch.equal(d["labels"], fl[i, :int(fc[i])])
                     for i, d in enumerate(dets))
     ok = ok and int(fc.min()) > 0
+    # the same through the ring (period 2: one full round, then a flush of one step)
+    ring = sharding.DetectionGatherRing(hi - lo, D, 2, dev)
+    outs = [ring.add(ob, os_, ol, oc), ring.add(ob, os_, ol, oc)]
+    ok = ok and outs[0] is None and outs[1] is not None
+    outs[1] = (outs[1][0].clone(), outs[1][1].clone())
+    ok = ok and ring.add(ob, os_, ol, oc) is None
+    last = ring.flush()
+    for g_p, g_c in (outs[1], last):
+        for k in range(g_p.shape[1]):
+            sp = g_p[:, k].reshape(B, D, 6)
+            ok = ok and torch.equal(sp[..., :4], fb) and torch.equal(sp[..., 4], fs) and torch.equal(sp[..., 5].to(torch.int64), fl)
+            ok = ok and torch.equal(g_c[:, k].reshape(B).to(torch.int32), fc)
+    ok = ok and outs[1][0].shape[1] == 2 and last[0].shape[1] == 1
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
