@@ -85,8 +85,10 @@ int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_
  * neighbouring rows spatially adjacent -- a pyramid level as torchvision's AnchorGenerator.grid_anchors emits it
  * (order y, x, a: row_len = grid_w * anchors per location, rows = grid_h; anchor_utils.py of torchvision 0.16.2).
  * The kernels then form their 256-anchor tiles from 4 rows x 64 anchors instead of 256 consecutive ones wherever a grid
- * allows it (first a multiple of 256, row_len of 64, rows of 4), which tightens the tiles' bounding boxes; other grids
- * are ignored.  Results do not depend on the hint.  Grids must be ascending, disjoint and inside [0, n) (OD_ERR_ARG).
+ * has at least 4 rows of at least 64 anchors and at least 16384 anchors in all (a row length that is not a multiple of
+ * 64, or a row count that is not a multiple of 4, makes the last tiles of a row / of the grid overlap their neighbours;
+ * grids for which that would cost more than a quarter more tiles are tiled consecutively), which tightens the tiles'
+ * bounding boxes.  Results do not depend on the hint.  Grids must be ascending, disjoint and inside [0, n) (OD_ERR_ARG).
  */
 int od_match_retinanet_grids(const float* anchors, int64_t anchor_batch_stride, int64_t n, const int64_t* anchor_grids,
                              int32_t num_grids, const float* gt_boxes, const int32_t* gt_offsets, int64_t m_total,

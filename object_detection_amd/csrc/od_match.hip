@@ -86,39 +86,54 @@ __device__ __forceinline__ int get_argmax(const MatchWs& ws, long long i) {
 __device__ __forceinline__ long long entry_base(int b, int m0) { return (long long)HCAP_PER_GT * m0 + 256ll * b; }
 __device__ __forceinline__ long long entry_cap(int M) { return (long long)HCAP_PER_GT * M + 256; }
 
-// Which 256 anchors form wave tile `wt`.  By default the consecutive ones.  Where the caller has said that a range of
-// the anchor list is a grid (`rows` rows of `row_len` anchors, neighbouring rows spatially adjacent: a pyramid level in
-// (y, x, a) order) and the range fits (start a multiple of 256, row_len a multiple of 64, rows a multiple of R), a tile
-// is R rows x 64 anchors instead: R runs of 64 consecutive anchors, one below the other.  Its bounding box is a
-// fraction as wide, so it meets fewer GT (finest level of a 1024 x 1024 image: 2.2 -> 1.5 GT per tile), and the loads
-// and stores stay 1 KiB / 512 B runs.  Any assignment of anchors to tiles gives the same results; the tile numbers
-// [0, wtiles) and the number of anchors per tile do not change.
+// Which 256 anchors form wave tile `wt`.  The anchor list is cut into segments; a plain segment is tiled by 256
+// consecutive anchors.  Where the caller has said that a range of the list is a grid (`rows` rows of `row_len`
+// anchors, neighbouring rows spatially adjacent: a pyramid level in (y, x, a) order) with at least R rows of at least 64
+// anchors, a tile is R rows x 64 anchors instead: R runs of 64 consecutive anchors, one below the other.  Its bounding
+// box is a fraction as wide, so it meets fewer GT (finest level of a 1024 x 1024 image: 2.2 -> 1.5 GT per tile), and
+// the loads and stores stay 1 KiB / 512 B runs.  A row length that is not a multiple of 64 (a row count that is not a
+// multiple of R) makes the last column (band) of tiles start 64 anchors (R rows) before the end of the row (grid), so
+// it overlaps its neighbour; likewise the last tile of a plain segment may reach into the next segment.  An anchor that
+// belongs to two tiles is simply processed twice: every tile computes the same values for it (a GT a tile skips has
+// IoU 0 with all its anchors), every write is of the same value, the row maxima are idempotent, and a duplicated
+// entry restores the same anchors again.  Any assignment of anchors to tiles gives the same results.
 constexpr int MAX_GRIDS = 8;
-struct TileLayout {
-    int grids;                       // 0: consecutive tiles everywhere
-    int tile_begin[MAX_GRIDS];       // first wave tile of the grid
-    int tile_end[MAX_GRIDS];         // one past its last
-    int runs[MAX_GRIDS];             // 64-anchor runs per row (row_len / 64)
-    float inv_runs[MAX_GRIDS];
-    int row_len[MAX_GRIDS];
+constexpr int MAX_SEGMENTS = MAX_GRIDS + 1;        // the described grids (tiled as grids or not) and what follows them
+struct TileLayout {                  // four words per segment: they travel in scalar registers from the kernel's start
+    int segments;
+    int tile_end[MAX_SEGMENTS];      // one past the last wave tile of segment s (it starts where segment s - 1 ends)
+    int first[MAX_SEGMENTS];         // its first anchor (layouts are only used for lists of fewer than 2^31 anchors)
+    int row_len[MAX_SEGMENTS];       // grid: anchors per row; plain segment: 0
+    int rows[MAX_SEGMENTS];
 };
 
-// first anchor of each of the R runs of wave tile wt (wave-uniform)
+// first anchor of each of the R runs of wave tile wt (the same for all lanes of a wave)
 __device__ __forceinline__ void tile_runs(const TileLayout& L, int wt, long long (&first)[R]) {
+    const int wtu = __builtin_amdgcn_readfirstlane(wt);               // scalar arithmetic from here on
+    int sbegin = 0, sfirst = 0, srow = 0, srows = 0;                   // no layout: one plain segment from anchor 0
 #pragma unroll
-    for (int r = 0; r < R; ++r) first[r] = (long long)wt * WTILE + r * 64;
-#pragma unroll
-    for (int l = 0; l < MAX_GRIDS; ++l) {
-        if (l < L.grids && wt >= L.tile_begin[l] && wt < L.tile_end[l]) {
-            const int tl = wt - L.tile_begin[l];
-            int bi = (int)((float)tl * L.inv_runs[l]);           // tl / runs, corrected below (tl < 2^24)
-            if (bi * L.runs[l] > tl) --bi;
-            if ((bi + 1) * L.runs[l] <= tl) ++bi;
-            const int bj = tl - bi * L.runs[l];
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                first[r] = (long long)L.tile_begin[l] * WTILE + (long long)(R * bi + r) * L.row_len[l] + 64 * bj;
+    for (int k = 0; k < MAX_SEGMENTS; ++k) {
+        const int begin = k == 0 ? 0 : L.tile_end[k - 1];
+        if (k < L.segments && wtu >= begin && wtu < L.tile_end[k]) {
+            sbegin = begin; sfirst = L.first[k]; srow = L.row_len[k]; srows = L.rows[k];
         }
+    }
+    const int tl = wtu - sbegin;
+    if (srow == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) first[r] = (long long)sfirst + ((long long)tl * WTILE + r * 64);
+    } else {
+        const int cols = (srow + 63) >> 6;                             // tiles per band
+        int bi = (int)((float)tl * __builtin_amdgcn_rcpf((float)cols));   // tl / cols, corrected below (tl < 2^24)
+        if (bi * cols > tl) --bi;
+        if ((bi + 1) * cols <= tl) ++bi;
+        const int bj = tl - bi * cols;
+        int row0 = R * bi, col0 = 64 * bj;
+        row0 = row0 < srows - R ? row0 : srows - R;                    // last band / column: flush with the end
+        col0 = col0 < srow - 64 ? col0 : srow - 64;
+        const int base = sfirst + row0 * srow + col0;                  // < 2^31: layouts are used below that only
+#pragma unroll
+        for (int r = 0; r < R; ++r) first[r] = (long long)(base + r * srow);
     }
 }
 
@@ -855,8 +870,12 @@ static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base
     return (size_t)HCAP_PER_GT * (size_t)(m_total > 0 ? m_total : 0) + 256 * (size_t)batch;
 }
 
+// Most wave tiles a layout can have: grids are tiled as grids only if that costs at most a quarter more tiles than plain
+// tiling (+1 each), and every plain segment rounds up once.
+static size_t tiles_cap(int64_t n) { return (size_t)((n + WTILE - 1) / WTILE) * 5 / 4 + 8 * MAX_SEGMENTS; }
+
 static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[9]) {
-    const size_t wtiles = (size_t)((n + WTILE - 1) / WTILE);
+    const size_t wtiles = tiles_cap(n);
     const size_t tiles = (size_t)batch * wtiles;
     off[0] = 0;                                                                     // gt_max_key
     off[1] = off[0] + align256((size_t)(m_total > 0 ? m_total : 0) * GSTRIDE * sizeof(uint32_t));   // argmax
@@ -890,25 +909,47 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                                         int32_t batch, float high, float low, int32_t allow_low_quality,
                                         int64_t* matched, void* workspace, size_t workspace_bytes, void* stream) {
     if (n < 0 || batch < 0 || m_total < 0 || num_grids < 0 || (num_grids > 0 && !anchor_grids)) return OD_ERR_ARG;
-    // A grid the tiles cannot follow (see TileLayout) is simply not used; grids must lie inside [0, n), ascending and
-    // disjoint, else the argument is wrong.
+    // Segments of the anchor list (see TileLayout): the grids that can be tiled as grids, plain stretches elsewhere.
+    // Grids must lie inside [0, n), ascending and disjoint, else the argument is wrong.
     TileLayout layout;
     memset(&layout, 0, sizeof(layout));
+    long long wtiles_ll = 0;
     {
-        int64_t prev_end = 0;
+        bool fits = true;                        // false: more segments than the layout holds -> one plain segment
+        auto add_segment = [&](int64_t first, int64_t len, int64_t row_len, int64_t rows) {
+            if (len <= 0) return;
+            if (layout.segments == MAX_SEGMENTS) { fits = false; return; }
+            const int k = layout.segments++;
+            layout.first[k] = (int)first;
+            layout.row_len[k] = (int)row_len;
+            layout.rows[k] = (int)rows;
+            wtiles_ll += row_len > 0 ? ((row_len + 63) / 64) * ((rows + R - 1) / R) : (len + WTILE - 1) / WTILE;
+            layout.tile_end[k] = (int)(wtiles_ll < 0x7fffffff ? wtiles_ll : 0x7fffffff);
+        };
+        int64_t prev_end = 0, plain_from = 0;
         for (int32_t i = 0; i < num_grids; ++i) {
             const int64_t first = anchor_grids[3 * i], row_len = anchor_grids[3 * i + 1], rows = anchor_grids[3 * i + 2];
             if (first < prev_end || row_len <= 0 || rows <= 0 || row_len > 0x7fffffffll || rows > 0x7fffffffll) return OD_ERR_ARG;
             if (row_len * rows > n - first) return OD_ERR_ARG;
             prev_end = first + row_len * rows;
-            if (first % WTILE != 0 || row_len % 64 != 0 || rows % R != 0) continue;
-            if (prev_end / WTILE > 0xffffff || layout.grids == MAX_GRIDS) continue;
-            const int k = layout.grids++;
-            layout.tile_begin[k] = (int)(first / WTILE);
-            layout.tile_end[k] = (int)(prev_end / WTILE);
-            layout.runs[k] = (int)(row_len / 64);
-            layout.inv_runs[k] = 1.0f / (float)layout.runs[k];
-            layout.row_len[k] = (int)row_len;
+            // worth tiling as a grid: whole 64-anchor runs and R rows exist, the overlapping last column / band does not
+            // inflate the number of tiles by more than a quarter, and the grid is a large one (at least 64 tiles).  The
+            // tiles of a small grid -- a coarse pyramid level, large anchors -- meet most GT whatever their shape;
+            // tighter boxes there only move tiles from the cooperative kernel to single waves with long serial loops
+            // (measured on the 32 x 32 level of the 1024 x 1024 pyramid: assign kernel 49 -> 54 us).
+            const int64_t tiles = ((row_len + 63) / 64) * ((rows + R - 1) / R);
+            const int64_t plain_tiles = (row_len * rows + WTILE - 1) / WTILE;
+            if (row_len < 64 || rows < R || plain_tiles < 64 || tiles * 4 > plain_tiles * 5 + 4) continue;
+            add_segment(plain_from, first - plain_from, 0, 0);
+            add_segment(first, row_len * rows, row_len, rows);
+            plain_from = prev_end;
+        }
+        add_segment(plain_from, n - plain_from, 0, 0);
+        if (!fits || n > 0x7fffffffll) {
+            memset(&layout, 0, sizeof(layout));
+            wtiles_ll = 0;
+            fits = true;
+            add_segment(0, n, 0, 0);
         }
     }
     if (n == 0 || batch == 0) return OD_OK;
@@ -921,9 +962,10 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
     hipStream_t s = (hipStream_t)stream;
     size_t off[9];
     match_ws_layout(m_total, batch, n, off);
-    const int wtiles = (int)((n + WTILE - 1) / WTILE);
+    if (wtiles_ll > (long long)tiles_cap(n)) return OD_ERR_WORKSPACE;         // cannot happen: see tiles_cap
+    const int wtiles = (int)wtiles_ll;
     const long long total_tiles = (long long)batch * wtiles;
-    if (total_tiles > 0x7fffffff || (long long)wtiles * m_total > 0x7fffffffll) return OD_ERR_LIMIT;   // int counters
+    if (total_tiles > 0x7fffffff || (long long)wtiles * m_total > 0x7fffffffll || wtiles >= (1 << 24)) return OD_ERR_LIMIT;   // int counters
     MatchWs ws;
     char* w = (char*)workspace;
     ws.gt_max_key = (uint32_t*)(w + off[0]);

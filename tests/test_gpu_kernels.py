@@ -62,12 +62,16 @@ def _grids_of(grids, per_location):
 @pytest.mark.parametrize("m", [7, 100, 700])
 def test_match_retinanet_anchor_grids(device, m):
     """The hint about the order of the anchor list (od_match_retinanet_grids) changes which anchors share a tile and
-    nothing else: same matches as the scalar checker and as the call without the hint -- on a pyramid whose first
-    level the tiles can follow and whose other levels they cannot (9 anchors per cell), on one where every level
-    qualifies (1 anchor per cell), with an anchor count that is not a multiple of the tile size, with a table per
-    image, with GT that overlap nothing, with an image without GT."""
+    nothing else: same matches as the scalar checker and as the call without the hint -- on power-of-two pyramids with
+    9 and with 1 anchor per cell, on pyramids whose row lengths and row counts are not multiples of the tile's 64
+    anchors and 4 rows (overlapping tiles), with an anchor count that is not a multiple of the tile size, with a table
+    per image, with GT that overlap nothing, with an image without GT."""
     cases = [((512, 512), (64, 32, 16, 8, 4), synthetic.retinanet_anchor_sizes(5, 32), (0.5, 1.0, 2.0)),
-             ((512, 512), (128, 64, 5), ((16,), (32,), (64,)), (1.0,))]
+             ((512, 512), (128, 64, 5), ((16,), (32,), (64,)), (1.0,)),
+             # rows of 900 / 450 / ... anchors and 100 / 50 / ... rows: on the two finest levels the last column and the
+             # last band of tiles overlap their neighbours; the small coarse levels are tiled consecutively
+             ((800, 800), (100, 50, 25, 13, 7), synthetic.retinanet_anchor_sizes(5, 32), (0.5, 1.0, 2.0)),
+             ((1000, 1000), (250, 130), ((16,), (32,)), (1.0,))]
     for image, grids, sizes, ratios in cases:
         ag, anchors = _anchors_cpu(image, grids, sizes, ratios)
         hint = _grids_of(grids, len(sizes[0]) * len(ratios))
