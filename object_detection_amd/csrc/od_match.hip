@@ -235,12 +235,16 @@ __device__ __forceinline__ uint32_t score_gt(const WaveTile& t, int g, float gx1
 
 __global__ __launch_bounds__(MT) void match_assign_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
-    const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
+    int image_fastest, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
     float high, float low, long long* __restrict__ matched) {
     const int lane = threadIdx.x & 63;
-    const int b = blockIdx.y;
-    // coarse (GT-heavy) pyramid levels sit at the end of the anchor list: start them first
-    const int wt = wtiles - 1 - (int)(blockIdx.x * (MT / 64) + (threadIdx.x >> 6));
+    // Workgroups are handed out x-fastest.  x = image, y = tile block: the same tiles of all images start together,
+    // and the coarse (GT-heavy) pyramid levels, which sit at the end of the anchor list, start first -- with the image
+    // as the slow index the last image's long tiles started when the kernel was nearly done and ran on as its tail.
+    // (Anchor lists with more tile blocks than y can hold fall back to x = tile block, y = image.)
+    const int b = image_fastest ? blockIdx.x : blockIdx.y;
+    const int tb = image_fastest ? blockIdx.y : blockIdx.x;
+    const int wt = wtiles - 1 - (int)(tb * (MT / 64) + (threadIdx.x >> 6));
     if (wt < 0) return;
     long long first[R];
     tile_runs(layout, wt, first);
@@ -978,7 +982,9 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
     ws.heavy_entries = (uint4*)(w + off[7]);
     ws.list_stride = total_tiles;
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
-    dim3 grid((unsigned)((wtiles + MT / 64 - 1) / (MT / 64)), (unsigned)batch);
+    const unsigned tile_blocks = (unsigned)((wtiles + MT / 64 - 1) / (MT / 64));
+    const int image_fastest = tile_blocks <= 65535u ? 1 : 0;
+    dim3 grid = image_fastest ? dim3((unsigned)batch, tile_blocks) : dim3(tile_blocks, (unsigned)batch);
     {
         const long long init_threads = m_total > batch ? m_total : batch;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_INIT, match_init_kernel, dim3((unsigned)((init_threads + 255) / 256)), dim3(256),
@@ -986,7 +992,7 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
     }
     const long long stride = (long long)anchor_batch_stride;
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
-                     (long long)n, wtiles, layout, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
+                     (long long)n, wtiles, layout, image_fastest, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
                      (long long*)matched);
     if (m_total > HEAVY) {
         int heavy_y = 4096 / batch > 64 ? 4096 / batch : 64;
