@@ -43,8 +43,15 @@ constexpr int MT = 256;          // threads per workgroup = 4 independent waves
 #endif
 constexpr int R = OD_R;          // anchors per lane
 constexpr int WTILE = 64 * R;    // anchors per wave
-constexpr int HEAVY = 24;        // a wave tile meeting more GT than this goes to the cooperative kernel
-constexpr int LCAP = HEAVY;      // entries of a light wave tile: one per GT with positive IoU
+constexpr int HEAVY = 24;        // a wave tile meeting more GT than this goes to the cooperative kernel ...
+constexpr int HEAVY_DENSE = 48;  // ... in an image with more than DENSE_GT boxes: more than this.  With dense targets every
+constexpr int DENSE_GT = 256;    // tile meets tens of GT and the cooperative kernel's per-tile cost (four waves that load
+                                 // the tile and walk the GT list) is better spent on the tiles that meet hundreds
+                                 // (2000 GT per image: 69 -> 57 us per image with 48 instead of 24; 100 GT per image: the
+                                 // assign kernel 49.7 -> 53.6 us)
+constexpr int LCAP = HEAVY_DENSE;   // entry slots of a light wave tile: one per GT with positive IoU
+__device__ __forceinline__ int heavy_threshold(int M) { return M > DENSE_GT ? HEAVY_DENSE : HEAVY; }
+static_assert(LCAP % HEAVY == 0, "the restore kernel walks the entry slots in steps of HEAVY");
 #ifndef OD_HT
 #define OD_HT 256
 #endif
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         maskA = __ballot(lane < M && overlaps_tile(t, gA));
         maskB = __ballot(64 + lane < M && overlaps_tile(t, gB));
     }
-    if (M > HEAVY) {                                 // count the GT this tile meets; queue it if heavy
+    const int heavy_thr = heavy_threshold(M);
+    if (M > heavy_thr) {                             // count the GT this tile meets; queue it if heavy
         int cnt = __popcll(maskA) + __popcll(maskB);
         if (M > RESIDENT) {
             for (int g0 = 0; g0 < M; g0 += 64) {
@@ -286,10 +294,10 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
                 bool ok = g < M;
                 if (ok) ok = overlaps_tile(t, gt[m0 + g]);
                 cnt += __popcll(__ballot(ok));
-                if (M > COUNT_ALL && cnt > HEAVY) break;      // wave-uniform; dense images: every tile is heavy
+                if (M > COUNT_ALL && cnt > heavy_thr) break;  // wave-uniform; dense images: most tiles are heavy
             }
         }
-        if (cnt > HEAVY) {
+        if (cnt > heavy_thr) {
             if (lane == 0) {                       // queue slot (the cooperative kernel reserves its entries itself)
                 const unsigned long long old = atomicAdd(ws.heavy_count + b * 16, 1ull << 32);
                 ws.heavy_queue[(long long)b * wtiles + (int)(old >> 32)] = make_int4(wt, 0, cnt, 0);
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(MT) void match_assign_kernel(
         if (want_restore && k > kZeroKey) {            // wave-uniform: this GT overlaps an anchor of the wave
             kreg = (lane == j) ? k : kreg;
             if (lane == 0) ws.wave_list[(long long)lcount * ws.list_stride + wslot] = make_uint2((uint32_t)(m0 + g), k);
-            ++lcount;                                  // <= HEAVY = LCAP for a light tile
+            ++lcount;                                  // <= heavy_thr <= LCAP for a light tile
         }
     };
     auto chunk_done = [&](int g0, uint32_t cur) {
@@ -639,56 +647,64 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     }
     // Heavy entries: consecutive entries belong to one tile and often hit together, so they are dealt to different
     // waves (entry = lane * waves + wave); light entries are slot-major already.
-    // A light block takes 256 neighbouring tiles at one entry slot (block -> slot and tile range by a scalar division,
-    // nothing per thread): items = LCAP * tile_blocks, dealt to the light blocks in turn.
+    // A light block takes 256 neighbouring tiles at one entry slot e < HEAVY (block -> slot and tile range by a scalar
+    // division, nothing per thread): items = HEAVY * tile_blocks, dealt to the light blocks in turn.  The slots from
+    // HEAVY on are only filled by tiles of images with more than DENSE_GT boxes: the block goes on to slot e + HEAVY
+    // if one of its tiles has that many entries.
     const long long nwaves = nthreads >> 6, wave_id = first >> 6;
     const long long tile_blocks = (total + 255) >> 8;
-    const long long light_items = tile_blocks * LCAP;
+    const long long light_items = tile_blocks * HEAVY;
     for (long long k0 = 0; light ? (k0 + blockIdx.x < light_items) : (k0 < limit); k0 += light ? (long long)light_blocks : nthreads) {
-        uint32_t word = 0u, key = 0u;
-        int wslot = 0;
-        bool have = false;
-        if (light) {                                     // slot-major: neighbouring threads, neighbouring tiles
-            const uint32_t item = (uint32_t)(k0 + blockIdx.x);          // < LCAP * 2^23: 32-bit division
-            const int e = (int)(item / (uint32_t)tile_blocks);
-            const long long tile = (long long)(item - (uint32_t)e * (uint32_t)tile_blocks) * 256 + threadIdx.x;
-            if (tile < total) {
-                wslot = (int)tile;
-                // the slot is read together with the tile's entry count (one memory round trip instead of two); a
-                // slot beyond the count holds stale data and is ignored
-                const uint2 ent = ws.wave_list[(long long)e * total + tile];
-                if (e < ws.wave_cnt[wslot]) {            // also skips heavy tiles (-2)
-                    word = ent.x; key = ent.y; have = true;
+        int pass = 0, more = 0;
+        do {
+            uint32_t word = 0u, key = 0u;
+            int wslot = 0, my_count = 0;
+            bool have = false;
+            if (light) {                                     // slot-major: neighbouring threads, neighbouring tiles
+                const uint32_t item = (uint32_t)(k0 + blockIdx.x);          // < HEAVY * 2^23: 32-bit division
+                const int e = (int)(item / (uint32_t)tile_blocks) + pass * HEAVY;
+                const long long tile = (long long)(item % (uint32_t)tile_blocks) * 256 + threadIdx.x;
+                if (tile < total) {
+                    wslot = (int)tile;
+                    // the slot is read together with the tile's entry count (one memory round trip instead of two); a
+                    // slot beyond the count holds stale data and is ignored
+                    const uint2 ent = ws.wave_list[(long long)e * total + tile];
+                    my_count = ws.wave_cnt[wslot];
+                    if (e < my_count) {                      // also skips heavy tiles (-2)
+                        word = ent.x; key = ent.y; have = true;
+                    }
+                }
+                ++pass;
+                more = (pass < LCAP / HEAVY) ? __syncthreads_or(my_count > e + HEAVY ? 1 : 0) : 0;
+            } else {
+                const long long i = k0 + (long long)lane * nwaves + wave_id;
+                if (i < limit) {
+                    const uint4 ent = ws.heavy_entries[ebase + i];
+                    wslot = (int)ent.x; word = ent.y; key = ent.z; have = true;
                 }
             }
-        } else {
-            const long long i = k0 + (long long)lane * nwaves + wave_id;
-            if (i < limit) {
-                const uint4 ent = ws.heavy_entries[ebase + i];
-                wslot = (int)ent.x; word = ent.y; key = ent.z; have = true;
+            bool hit = false;
+            if (have && key > kZeroKey) {
+                hit = key == ws.gt_max_key[(long long)word * GSTRIDE];
             }
-        }
-        bool hit = false;
-        if (have && key > kZeroKey) {
-            hit = key == ws.gt_max_key[(long long)word * GSTRIDE];
-        }
-        unsigned long long hits = __ballot(hit);         // the loop bounds are wave-uniform: all lanes are here
-        while (hits) {
-            int hs[RB], hg[RB];
-            uint32_t hk[RB];
+            unsigned long long hits = __ballot(hit);         // the loop bounds are wave-uniform: all lanes are here
+            while (hits) {
+                int hs[RB], hg[RB];
+                uint32_t hk[RB];
 #pragma unroll
-            for (int q = 0; q < RB; ++q) {
-                hs[q] = -1; hg[q] = 0; hk[q] = 0u;
-                if (hits) {
-                    const int src = __ffsll(hits) - 1;
-                    hits &= hits - 1;
-                    hs[q] = bcast_lane(wslot, src);
-                    hg[q] = bcast_lane((int)word, src);
-                    hk[q] = (uint32_t)bcast_lane((int)key, src);
+                for (int q = 0; q < RB; ++q) {
+                    hs[q] = -1; hg[q] = 0; hk[q] = 0u;
+                    if (hits) {
+                        const int src = __ffsll(hits) - 1;
+                        hits &= hits - 1;
+                        hs[q] = bcast_lane(wslot, src);
+                        hg[q] = bcast_lane((int)word, src);
+                        hk[q] = (uint32_t)bcast_lane((int)key, src);
+                    }
                 }
+                restore_row_segments(anchors, anchor_batch_stride, n, wtiles, layout, gt, gt_offsets, ws, hs, hg, hk, matched);
             }
-            restore_row_segments(anchors, anchor_batch_stride, n, wtiles, layout, gt, gt_offsets, ws, hs, hg, hk, matched);
-        }
+        } while (more);
     }
     if (overflow && hb / batch < hblocks) {   // one wave per (heavy tile, 64-GT chunk)
         const int chunks = (gt_offsets[hb_image + 1] - gt_offsets[hb_image] + 63) >> 6;
@@ -1002,7 +1018,7 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
-        const long long light_items = ((total_tiles + 255) / 256) * LCAP;       // (entry slot, 256 tiles)
+        const long long light_items = ((total_tiles + 255) / 256) * HEAVY;      // (entry slot below HEAVY, 256 tiles)
         const int light_blocks = (int)(light_items < 16384 ? light_items : 16384);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,

@@ -70,7 +70,7 @@ def main():
         m_total = sum(int(g.shape[0]) for g in gts)
         n = anchors.shape[-2]
         tiles = len(gts) * (((n + 255) // 256) * 5 // 4 + 8 * 9)      # the capacity the workspace is laid out for
-        off = a256(m_total * 4 * 32) + a256(len(gts) * n * 4) + a256(tiles * 4) + a256(tiles * 24 * 8) + a256(len(gts) * 4)
+        off = a256(m_total * 4 * 32) + a256(len(gts) * n * 4) + a256(tiles * 4) + a256(tiles * 48 * 8) + a256(len(gts) * 4)
         ws = kernels._workspaces[(anchors.device.index, torch.cuda.current_stream(anchors.device).cuda_stream, "match")]
         hc = ws[off + 256:off + 256 + len(gts) * 128].view(torch.int64)[::16]
         res["match_counters"] = {"heavy_tiles": int((hc >> 32).sum()), "heavy_entries": int((hc & 0xffffffff).sum()),
