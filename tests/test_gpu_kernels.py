@@ -82,7 +82,13 @@ def test_match_retinanet_anchor_grids(device, m):
         g_d = [g.to(device) for g in gts]
         for lq in (True, False):
             plain = kernels.match_retinanet(anchors.to(device), g_d, 0.6, 0.5, lq, grids=()).cpu()
-            hinted = kernels.match_retinanet(anchors.to(device), g_d, 0.6, 0.5, lq, grids=hint).cpu()
+            # an anchor that no tile covered would keep whatever the output buffer held: make that a value no match can
+            # be (the allocator hands the block just freed to the next request of the same size)
+            poison = torch.full((len(gts), anchors.shape[0]), -7, dtype=torch.int64, device=device)
+            del poison
+            hinted = kernels.match_retinanet(anchors.to(device), g_d, 0.6, 0.5, lq, grids=hint)
+            assert int(hinted.min()) >= -2
+            hinted = hinted.cpu()
             assert torch.equal(plain, hinted), (grids, lq)
             for b, g in enumerate(gts):
                 assert np.array_equal(hinted[b].numpy(), c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, lq)), (grids, lq, b)
