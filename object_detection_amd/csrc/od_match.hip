@@ -737,13 +737,16 @@ constexpr int FGCH = 1024;
 __global__ __launch_bounds__(FT) void match_fcos_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, long long n_first,
     long long n_last, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, float radius,
-    long long* __restrict__ matched) {
+    long long* __restrict__ matched, int image_fastest) {
     __shared__ float4 s_g[FGCH];
     __shared__ float s_best[FW][64];
     __shared__ int s_bi[FW][64];
-    const int b = blockIdx.y;
+    // workgroups are handed out x-fastest: x = image, y = anchor block, the last blocks (coarse levels: every GT
+    // survives the culling there, the longest loops) first; lists with more blocks than y holds: x = block, y = image
+    const int b = image_fastest ? blockIdx.x : blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + lane;
+    const long long blk = image_fastest ? (long long)(gridDim.y - 1 - blockIdx.y) : (long long)blockIdx.x;
+    const long long idx = blk * 64 + lane;
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     const bool valid = idx < n;
@@ -1039,11 +1042,13 @@ extern "C" int od_match_fcos(const float* anchors, int64_t anchor_batch_stride, 
     if (((uintptr_t)anchors & 15) || ((uintptr_t)gt_boxes & 15)) return OD_ERR_ARG;
     if (n_first_level < 0 || n_last_level < 0 || n_first_level > n || n_last_level > n) return OD_ERR_ARG;
     if (batch > 65535 || (n + 63) / 64 > 0x7fffffffll) return OD_ERR_LIMIT;
-    dim3 grid((unsigned)((n + 63) / 64), (unsigned)batch);
+    const long long blocks = (n + 63) / 64;
+    const int image_fastest = blocks <= 65535 ? 1 : 0;
+    dim3 grid = image_fastest ? dim3((unsigned)batch, (unsigned)blocks) : dim3((unsigned)blocks, (unsigned)batch);
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_FCOS, match_fcos_kernel, grid, dim3(FT), 0, (hipStream_t)stream,
                      (const float4*)anchors, (long long)anchor_batch_stride, (long long)n, (long long)n_first_level,
                      (long long)n_last_level, (const float4*)gt_boxes, gt_offsets, center_sampling_radius,
-                     (long long*)matched);
+                     (long long*)matched, image_fastest);
     return OD_OK;
 }
 
