@@ -610,13 +610,18 @@ __device__ __forceinline__ void restore_row_segments(const float4* __restrict__ 
 constexpr int ZB = 8;
 __global__ __launch_bounds__(256) void match_restore_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
-    int batch, int light_blocks, int heavy_blocks, const float4* __restrict__ gt, const int* __restrict__ gt_offsets,
-    MatchWs ws, long long* __restrict__ matched) {
+    int batch, int light_blocks, int heavy_blocks, int heavy_first, const float4* __restrict__ gt,
+    const int* __restrict__ gt_offsets, MatchWs ws, long long* __restrict__ matched) {
     const long long total = (long long)batch * wtiles;
     const int lane = threadIdx.x & 63;
-    const bool light = (int)blockIdx.x < light_blocks;
+    // Block order = hand-out order.  With dense targets nearly every tile is a heavy one and the heavy-entry blocks are
+    // the long ones: they (and the zero-maximum blocks) go first (2000 GT per image: 150 -> 118 us for 32 images);
+    // otherwise they have little to do and the light blocks go first (100 GT per image: 17.5 against 18.3 us).
+    const int special = heavy_blocks + batch * ZB;
+    const bool light = heavy_first ? (int)blockIdx.x >= special : (int)blockIdx.x < light_blocks;
+    const int lb = heavy_first ? (int)blockIdx.x - special : (int)blockIdx.x;        // light block number
     // light blocks share one index space; heavy blocks are dealt round-robin to the images
-    const int hb = (int)blockIdx.x - light_blocks;
+    const int hb = heavy_first ? (int)blockIdx.x : (int)blockIdx.x - light_blocks;
     if (!light && hb >= heavy_blocks) {                                  // zero-maximum blocks
         const int zb = hb - heavy_blocks;
         const int b = zb / ZB, part = zb - b * ZB;
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     const int hblocks = heavy_blocks / batch;                            // heavy blocks per image
     const int hb_image = light ? 0 : hb % batch;
     const long long nthreads = (long long)(light ? light_blocks : hblocks) * 256;
-    const long long first = (long long)(light ? (int)blockIdx.x : hb / batch) * 256 + (threadIdx.x & ~63);
+    const long long first = (long long)(light ? lb : hb / batch) * 256 + (threadIdx.x & ~63);
     long long limit = total * LCAP, ebase = 0;
     bool overflow = false;
     int nheavy = 0;
@@ -654,14 +659,14 @@ __global__ __launch_bounds__(256) void match_restore_kernel(
     const long long nwaves = nthreads >> 6, wave_id = first >> 6;
     const long long tile_blocks = (total + 255) >> 8;
     const long long light_items = tile_blocks * HEAVY;
-    for (long long k0 = 0; light ? (k0 + blockIdx.x < light_items) : (k0 < limit); k0 += light ? (long long)light_blocks : nthreads) {
+    for (long long k0 = 0; light ? (k0 + lb < light_items) : (k0 < limit); k0 += light ? (long long)light_blocks : nthreads) {
         int pass = 0, more = 0;
         do {
             uint32_t word = 0u, key = 0u;
             int wslot = 0, my_count = 0;
             bool have = false;
             if (light) {                                     // slot-major: neighbouring threads, neighbouring tiles
-                const uint32_t item = (uint32_t)(k0 + blockIdx.x);          // < HEAVY * 2^23: 32-bit division
+                const uint32_t item = (uint32_t)(k0 + lb);                  // < HEAVY * 2^23: 32-bit division
                 const int e = (int)(item / (uint32_t)tile_blocks) + pass * HEAVY;
                 const long long tile = (long long)(item % (uint32_t)tile_blocks) * 256 + threadIdx.x;
                 if (tile < total) {
@@ -1027,7 +1032,8 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
                          dim3((unsigned)(light_blocks + heavy_entry_blocks + batch * ZB)), dim3(256), 0, s,
                          (const float4*)anchors, stride, (long long)n, wtiles, layout, (int)batch, light_blocks,
-                         heavy_entry_blocks, (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
+                         heavy_entry_blocks, (m_total > (long long)DENSE_GT * batch) ? 1 : 0, (const float4*)gt_boxes,
+                         gt_offsets, ws, (long long*)matched);
     }
     return OD_OK;
 }
