@@ -159,6 +159,8 @@ def main():
         apl = [anchors] * cfg.batch
 
         def fused_step():
+            for v in head.values():               # leaves here (in a model the head outputs are not): without this the
+                v.grad = None                     # step would also time the accumulation into 400 MB of old gradients
             losses = model.compute_loss(targets, head, apl)
             (losses["classification"] + losses["bbox_regression"]).backward()
 
@@ -183,6 +185,8 @@ def main():
             return (1 - inter / (union + 1e-7) + (area_c - union) / (area_c + 1e-7)).sum()
 
         def torch_step():
+            for v in head.values():
+                v.grad = None
             matched = model.match_anchors(targets, apl)
             cls_losses, reg_losses = [], []
             for t, logits, reg, m in zip(targets, head["cls_logits"], head["bbox_regression"], matched):
