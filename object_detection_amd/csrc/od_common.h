@@ -107,6 +107,17 @@ __device__ __forceinline__ float wave_fmin_all(float v) {
     return ordered_key_inv(~wave_umax_all(~ordered_key(v)));
 }
 
+__device__ __forceinline__ uint32_t wave_or_all(uint32_t v) {
+    v |= dpp_u32<0x111>(v);
+    v |= dpp_u32<0x112>(v);
+    v |= dpp_u32<0x114>(v);
+    v |= dpp_u32<0x118>(v);
+    v |= dpp_u32<0x142, 0xa>(v);
+    v |= dpp_u32<0x143, 0xc>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ uint32_t wave_and_all(uint32_t v) { return ~wave_or_all(~v); }
+
 __device__ __forceinline__ uint32_t wave_sum_all(uint32_t v) {
     v += dpp_u32<0x111>(v);
     v += dpp_u32<0x112>(v);
@@ -221,6 +232,38 @@ __device__ __forceinline__ float box_area(float x1, float y1, float x2, float y2
 // wave) or through LDS (partners in another wave); only the last kind needs barriers: 10 LDS stages for
 // n_pad = 1024 or 4096 instead of 55 or 78.  Keys must be in s[0, n_pad) and visible (barrier) on entry;
 // on return they are sorted and visible to all threads.
+// Value of lane (lane ^ LX) for LX = 1, 2, 4, 8 through DPP moves (the partner is in the lane's row of 16: no trip
+// through the LDS crossbar that a general shuffle makes); other distances use the shuffle.
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long old, unsigned long long v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)old, (int)(uint32_t)v, CTRL, 0xf, BANK_MASK, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(old >> 32), (int)(uint32_t)(v >> 32), CTRL, 0xf,
+                                                              BANK_MASK, false);
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int LX>
+__device__ __forceinline__ unsigned long long xor_lane_u64(unsigned long long v) {
+    if (LX == 1) return dpp_u64<0xB1, 0xf>(v, v);                       // quad_perm [1,0,3,2]
+    if (LX == 2) return dpp_u64<0x4E, 0xf>(v, v);                       // quad_perm [2,3,0,1]
+    if (LX == 4) return dpp_u64<0x114, 0xa>(dpp_u64<0x104, 0x5>(v, v), v);   // row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3
+    if (LX == 8) return dpp_u64<0x128, 0xf>(v, v);                      // row_ror:8
+    return __shfl_xor(v, LX);
+}
+
+// One compare-exchange stage of the bitonic network between lanes LX apart (element stride LX * E), sequence length k.
+template <int LX, int E>
+__device__ __forceinline__ void bitonic_lane_stage(unsigned long long (&v)[E], int base, int k) {
+    constexpr int j = LX * E;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int i = base + e;
+        const unsigned long long o = xor_lane_u64<LX>(v[e]);
+        const bool keep_larger = ((i & j) == 0) == ((i & k) == 0);
+        const bool o_larger = o > v[e];
+        v[e] = (o_larger == keep_larger) ? o : v[e];
+    }
+}
+
 template <int E, int NT>
 __device__ __forceinline__ void bitonic_sort_desc_impl(unsigned long long* s, int n_pad) {
     const int tid = threadIdx.x;
@@ -256,17 +299,13 @@ __device__ __forceinline__ void bitonic_sort_desc_impl(unsigned long long* s, in
         }
         in_regs = true;
         if (on) {
-            for (; j >= E; j >>= 1) {             // partners in another lane of the wave
-                const int lx = j / E;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const int i = base + e;
-                    const unsigned long long o = __shfl_xor(v[e], lx);
-                    const bool keep_larger = ((i & j) == 0) == ((i & k) == 0);
-                    const bool o_larger = o > v[e];
-                    v[e] = (o_larger == keep_larger) ? o : v[e];
-                }
-            }
+            const int lx0 = j / E;                // partners in another lane of the wave: distances lx0, lx0 / 2, ... 1
+            if (lx0 >= 32) bitonic_lane_stage<32, E>(v, base, k);
+            if (lx0 >= 16) bitonic_lane_stage<16, E>(v, base, k);
+            if (lx0 >= 8) bitonic_lane_stage<8, E>(v, base, k);
+            if (lx0 >= 4) bitonic_lane_stage<4, E>(v, base, k);
+            if (lx0 >= 2) bitonic_lane_stage<2, E>(v, base, k);
+            if (lx0 >= 1) bitonic_lane_stage<1, E>(v, base, k);
 #pragma unroll
             for (int jj = E >> 1; jj >= 1; jj >>= 1) {   // partners in this thread's registers
                 if (jj <= (k >> 1)) {

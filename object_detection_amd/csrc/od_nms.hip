@@ -176,6 +176,10 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     const int nseg = a.lazy ? a.num_seg : 1;
     if (tid < WSEG) { s_head[tid] = 0; s_taken[tid] = 0; }
     if (tid == 0) { s_tmp[0] = 0; s_tmp[1] = 0; }   // [0] = kept count, [1] = done flag
+    // Segments that break the caller's promise of being sorted make ranks collide, which leaves entries of these two
+    // tables unwritten; starting from valid values keeps every later index inside its array (the result is then
+    // unspecified, but nothing is read or written out of bounds).
+    if (tid < S) { s_strip[tid] = 0; s_cpos[tid] = 0; }
     __syncthreads();
     const int n_valid = s_segpre[a.num_seg];
 

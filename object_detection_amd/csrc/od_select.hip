@@ -573,25 +573,26 @@ constexpr long long SAMPLE_IN_REGS = 2 * SEL_T * SU;           // larger samples
 constexpr int SAMPLE_PART = SEL_T * SU;                        // samples per workgroup of sample_part_kernel
 constexpr int SAMPLE_PARTS_MAX = (int)(SAMPLE_MAX / SAMPLE_PART);
 
-// rank keys (0: cannot pass the threshold) of the samples base + u * SEL_T + tid, u < SU
+// rank keys (0: cannot pass the threshold) of the samples base + u * SEL_T + tid, u < NU; all NU scattered loads of a
+// thread are requested before the first is used
+template <int NU>
 __device__ __forceinline__ void sample_keys(const FilterParams& p, int l, int b, const float* __restrict__ src,
                                             const SampleGeometry& g, uint32_t base, uint32_t* key) {
     const int tid = threadIdx.x;
-    float x[SU];
-    uint32_t pos[SU];
-#pragma unroll
-    for (int u = 0; u < SU; ++u) {
+    auto position = [&](int u) -> uint32_t {
         const uint32_t i = base + u * SEL_T + tid;
         const uint32_t run = i / SAMPLE_RUN;
-        pos[u] = run * g.window + __umulhi(run * 2654435761u, g.spread) + (i % SAMPLE_RUN);
-        x[u] = src[pos[u]];
-    }
+        return run * g.window + __umulhi(run * 2654435761u, g.spread) + (i % SAMPLE_RUN);
+    };
+    float x[NU];
 #pragma unroll
-    for (int u = 0; u < SU; ++u) {
+    for (int u = 0; u < NU; ++u) x[u] = src[position(u)];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
         key[u] = 0u;
         if (p.prefilter && x[u] <= p.pre_logit) continue;
         if (p.has_ctr) {
-            const float sc = score_of(p, l, b, x[u], flat_of(p, l, pos[u]));
+            const float sc = score_of(p, l, b, x[u], flat_of(p, l, position(u)));
             if (sc > p.thresh) key[u] = f2u(sc);
         } else {
             key[u] = ordered_bits(x[u]);
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(SEL_T) void sample_part_kernel(FilterParams p, unsi
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
     uint32_t* stash = sample_stash(p, keys, l, b);
     uint32_t key[SU];
-    sample_keys(p, l, b, src, g, (uint32_t)part * SAMPLE_PART, key);
+    sample_keys<SU>(p, l, b, src, g, (uint32_t)part * SAMPLE_PART, key);
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
         stash[(uint32_t)part * SAMPLE_PART + u * SEL_T + tid] = key[u];
@@ -652,7 +653,6 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
     const int r = g.r;
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
     constexpr int U = SU;
-    auto load_batch = [&](uint32_t base, uint32_t* key) { sample_keys(p, l, b, src, g, base, key); };
     const uint32_t* stash = sample_stash(p, keys, l, b);       // large samples: written by sample_part_kernel
     // up to 32 samples per thread stay in registers for the second pass; larger samples come from the stash
     const bool in_regs = S <= SAMPLE_IN_REGS;
@@ -661,10 +661,10 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
     for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
     __syncthreads();
     if (in_regs) {
-        load_batch(0, kreg);
         if (S > SEL_T * U) {
-            load_batch(SEL_T * U, kreg + U);
+            sample_keys<2 * U>(p, l, b, src, g, 0u, kreg);
         } else {
+            sample_keys<U>(p, l, b, src, g, 0u, kreg);
 #pragma unroll
             for (int u = 0; u < U; ++u) kreg[U + u] = 0u;
         }
@@ -758,7 +758,41 @@ __device__ __forceinline__ void lds_append(bool take, unsigned long long k, unsi
     }
 }
 
+// What the gather of a level reads through, fetched from the kernel's arguments once, at its start: the first read of
+// an argument line is a memory round trip, which is better not left for the moment the boxes are needed.
+struct LevelInputs {
+    const float* reg;
+    const float* anchors;
+    long long reg_stride, anchor_stride;
+    unsigned int plane, apl;
+};
+__device__ __forceinline__ LevelInputs level_inputs(const SelectParams& p, int l) {
+    LevelInputs li;
+    li.reg = p.reg[l]; li.anchors = p.anchors[l];
+    li.reg_stride = p.reg_stride[l]; li.anchor_stride = p.anchor_stride[l];
+    li.plane = p.plane[l]; li.apl = p.apl[l];
+    asm volatile("" :: "s"(li.reg), "s"(li.anchors), "s"(li.reg_stride), "s"(li.anchor_stride), "s"(li.plane), "s"(li.apl));
+    return li;
+}
+
+// The two inputs of a candidate's box: its regression values and its anchor (key = score bits << 32 | ~flat index).
+__device__ __forceinline__ void gather_candidate(const LevelInputs& li, int num_classes, int b, unsigned long long key,
+                                                 float4& r, float4& an) {
+    const uint32_t flat = 0xFFFFFFFFu - (uint32_t)key;
+    const uint32_t a = flat / (uint32_t)num_classes;
+    if (li.plane == 0) {
+        r = *reinterpret_cast<const float4*>(li.reg + ((long long)b * li.reg_stride + a) * 4);
+    } else {                                                     // channel (a_i*4 + k) of location hw
+        const uint32_t hw = a / li.apl;
+        const float* rp = li.reg + (long long)b * li.reg_stride * 4 + (long long)(a - hw * li.apl) * 4 * li.plane + hw;
+        r = make_float4(rp[0], rp[li.plane], rp[2ll * li.plane], rp[3ll * li.plane]);
+    }
+    an = *reinterpret_cast<const float4*>(li.anchors + ((long long)b * li.anchor_stride + a) * 4);
+}
+
+// Decodes, clips and writes the candidate of rank `rank` from its gathered inputs.
 __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b, unsigned long long key, int rank,
+                                             const float4 r, const float4 an,
                                              const int* __restrict__ image_hw, int num_levels,
                                              float* __restrict__ cand_boxes, float* __restrict__ cand_scores,
                                              int* __restrict__ cand_labels, long long* __restrict__ cand_index) {
@@ -766,15 +800,6 @@ __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b
     const float score = u2f((uint32_t)(key >> 32));
     const uint32_t a = flat / (uint32_t)p.num_classes;
     const int label = (int)(flat - a * (uint32_t)p.num_classes);
-    float4 r;
-    if (p.plane[l] == 0) {
-        r = *reinterpret_cast<const float4*>(p.reg[l] + ((long long)b * p.reg_stride[l] + a) * 4);
-    } else {                                                     // channel (a_i*4 + k) of location hw
-        const uint32_t hw = a / p.apl[l];
-        const float* rp = p.reg[l] + (long long)b * p.reg_stride[l] * 4 + (long long)(a - hw * p.apl[l]) * 4 * p.plane[l] + hw;
-        r = make_float4(rp[0], rp[p.plane[l]], rp[2ll * p.plane[l]], rp[3ll * p.plane[l]]);
-    }
-    const float4 an = *reinterpret_cast<const float4*>(p.anchors[l] + ((long long)b * p.anchor_stride[l] + a) * 4);
     float x1, y1, x2, y2;
     if (p.coder == OD_CODER_BOXCODER) {
         // BoxCoder.decode_single, weights (1,1,1,1): every product and sum rounded separately
@@ -803,6 +828,19 @@ __device__ __forceinline__ void decode_store(const SelectParams& p, int l, int b
     if (cand_index) cand_index[slot] = (long long)flat;
 }
 
+// Histogram increment with the lanes that share the first active lane's bin counted by one atomic: scores that
+// saturate (thousands of candidates at exactly 1.0) otherwise serialise 64 atomics per instruction on one counter.
+__device__ __forceinline__ void hist_add(unsigned int* s_hist, bool valid, unsigned int bin) {
+    const uint64_t act = __ballot(valid);
+    if (act == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int fl = __ffsll((unsigned long long)act) - 1;
+    const unsigned int fb = (unsigned int)__builtin_amdgcn_readlane((int)bin, fl);
+    const uint64_t same = __ballot(valid && bin == fb);
+    if (lane == fl) atomicAdd(&s_hist[fb], (unsigned int)__popcll(same));
+    if (valid && bin != fb) atomicAdd(&s_hist[bin], 1u);
+}
+
 __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_levels,
                                                        const unsigned long long* __restrict__ all_keys,
                                                        const unsigned int* __restrict__ key_count,
@@ -817,19 +855,32 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
                                                        int* __restrict__ cand_count) {
     __shared__ unsigned long long s_keys[CAP];
     __shared__ unsigned int s_hist[HBINS];
+    __shared__ unsigned long long s_red[2];
     __shared__ int s_tmp[32];
     const int tid = threadIdx.x;
     const int l = blockIdx.x, b = blockIdx.y;
     const int K = p.topk;
     const long long slot = (long long)b * num_levels + l;
-    unsigned int total = key_count[slot * CSTRIDE];
-    if (cuts[slot].active && key_valid[slot * CSTRIDE] < (unsigned int)K) total = key_count_redo[slot * CSTRIDE];
+    // four independent reads, requested together (a chain of conditional reads would be three round trips)
+    const unsigned int n_first = key_count[slot * CSTRIDE], n_valid = key_valid[slot * CSTRIDE];
+    const unsigned int n_redo = key_count_redo[slot * CSTRIDE];
+    const int cut_active = cuts[slot].active;
+    const unsigned int total = (cut_active && n_valid < (unsigned int)K) ? n_redo : n_first;
     const unsigned long long* keys = all_keys + (long long)b * p.keys_per_image + p.key_off[l];
     if (total == 0) {
         if (tid == 0) cand_count[b * num_levels + l] = 0;
         return;
     }
-    if (tid == 0) s_tmp[20] = 0;
+    const LevelInputs li = level_inputs(p, l);
+#ifdef OD_SEL_STAMPS
+    unsigned long long st[16];
+    int st_n = 0;
+#define SEL_STAMP() do { if (st_n < 16) st[st_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SEL_STAMP() do { } while (0)
+#endif
+    SEL_STAMP();
+    if (tid == 0) { s_tmp[20] = 0; s_tmp[21] = 0; }
     __syncthreads();
 
     // ---- phase 1: bring the keys that can still be among the best K into LDS ---------------------------
@@ -874,62 +925,133 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
         __syncthreads();            // s_tmp[20] is reused below
     }
 
+    SEL_STAMP();
     // ---- phase 2: radix refinement inside LDS until about K keys remain (the sort costs n log^2 n) ------
     int target = 64;
     while (target < K) target <<= 1;             // sorting fewer than this many keys gains nothing
-    while (cnt > target && w > 0) {
-        const int d = w < HBITS ? w : HBITS;
-        const int shift = w - d;
-        const int nb = 1 << d;
-        for (int i = tid; i < nb; i += SEL_T) s_hist[i] = 0;
-        if (tid == 0) s_tmp[20] = 0;
-        __syncthreads();
-        const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
+    if (cnt > target && w > 0) {
+        // The keys stay where they are (every thread holds its eight in registers) while the passes narrow the
+        // interval; they are compacted once, when few enough lie at or above its lower end.
         unsigned long long k[CAP / SEL_T];
 #pragma unroll
         for (int u = 0; u < CAP / SEL_T; ++u) {
             const int i = u * SEL_T + tid;
             k[u] = i < cnt ? s_keys[i] : 0ull;
-            if (k[u] != 0ull && k[u] >= lo && (k[u] - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k[u] - lo) >> shift)], 1u);
         }
-        __syncthreads();
-        find_cut_bin(s_hist, nb, need, s_tmp);
-        const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18], found = s_tmp[19];
-        int n_ge;
-        if (found) {
-            lo = lo + ((unsigned long long)bstar << shift);
-            w = shift;
-            n_ge = (K - need) + above + h;
-            need -= above;
-        } else {                                     // fewer valid keys than K (zero keys inflated cnt): keep them all
-            n_ge = (K - need) + above;               // `above` = all valid keys of the interval
-            w = 0;
+        int n_ge = cnt;
+        for (int pass = 0; n_ge > target && w > 0; ++pass) {
+            for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
+            if (tid == 0) { s_tmp[20] = 0; s_red[0] = ~0ull; s_red[1] = 0ull; }
+            __syncthreads();
+            SEL_STAMP();
+            if (pass > 0) {
+                // A pass that left too many keys met keys that agree in the bits it looked at (equal scores: thousands
+                // of saturated logits differ only in their index, 32 bits further down).  The bits that all keys of the
+                // interval share are skipped: AND and OR of (key - lo) differ first at the highest bit that varies.
+                const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
+                unsigned long long all_and = ~0ull, all_or = 0ull;
+#pragma unroll
+                for (int u = 0; u < CAP / SEL_T; ++u) {
+                    if (k[u] != 0ull && k[u] >= lo && (k[u] - lo) <= span) { all_and &= k[u] - lo; all_or |= k[u] - lo; }
+                }
+                all_and = ((unsigned long long)wave_and_all((uint32_t)(all_and >> 32)) << 32) | wave_and_all((uint32_t)all_and);
+                all_or = ((unsigned long long)wave_or_all((uint32_t)(all_or >> 32)) << 32) | wave_or_all((uint32_t)all_or);
+                if ((tid & 63) == 0 && all_or >= all_and) { atomicAnd(&s_red[0], all_and); atomicOr(&s_red[1], all_or); }
+                __syncthreads();
+                const unsigned long long a = s_red[0], o = s_red[1];
+                if (o >= a) {                                // the interval holds keys
+                    const unsigned long long diff = a ^ o;
+                    const int wn = diff ? 64 - __clzll((long long)diff) : 0;
+                    if (wn < w) { lo += (wn < 64) ? ((a >> wn) << wn) : 0ull; w = wn; }
+                }
+                if (w == 0) break;                           // one key value left in the interval
+            }
+            const int d = w < HBITS ? w : HBITS;
+            const int shift = w - d;
+            const int nb = 1 << d;
+            const unsigned long long span = (w >= 64) ? ~0ull : ((1ull << w) - 1);
+#pragma unroll
+            for (int u = 0; u < CAP / SEL_T; ++u) {
+                const bool in = k[u] != 0ull && k[u] >= lo && (k[u] - lo) <= span;
+                hist_add(s_hist, in, in ? (unsigned int)((k[u] - lo) >> shift) : 0u);
+            }
+            __syncthreads();
+            SEL_STAMP();
+            find_cut_bin(s_hist, nb, need, s_tmp);
+            SEL_STAMP();
+            const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18], found = s_tmp[19];
+            if (found) {
+                lo = lo + ((unsigned long long)bstar << shift);
+                w = shift;
+                n_ge = (K - need) + above + h;
+                need -= above;
+            } else {                                     // fewer valid keys than K (zero keys inflated cnt): keep them all
+                n_ge = (K - need) + above;               // `above` = all valid keys of the interval
+                w = 0;
+            }
         }
-        // compact in place: every thread holds its keys in registers, so the buffer can be rewritten
+        // compact in place: every thread holds its keys in registers, so the buffer can be rewritten (nothing reads
+        // it between the loads above and the barrier below)
 #pragma unroll
         for (int u = 0; u < CAP / SEL_T; ++u) lds_append(k[u] >= lo && k[u] != 0ull, k[u], s_keys, &s_tmp[20], CAP);
         __syncthreads();
         cnt = n_ge;
     }
     unsigned long long* sorted = s_keys;
+    SEL_STAMP();
 
     int n_pad = 64;
     while (n_pad < cnt) n_pad <<= 1;
+    // At most one key per thread (top-k up to 1024): the set of candidates is final, only their order is not.  Every
+    // thread requests the regression values and the anchor of its key now, the sort runs while those cold, scattered
+    // reads are on their way, and the key's place in the sorted list (found by bisection) says where the box goes.
+    const bool early = cnt <= SEL_T;
+    unsigned long long mine = 0ull;
+    float4 my_r = make_float4(0.f, 0.f, 0.f, 0.f), my_an = my_r;
+    if (early) {
+        if (tid < cnt) mine = sorted[tid];
+        if (mine != 0ull) gather_candidate(li, p.num_classes, b, mine, my_r, my_an);
+        // zero keys (slots the filter reserved for logits that then failed the exact threshold) do not count
+        const uint64_t bal = __ballot(mine != 0ull);
+        if ((tid & 63) == 0 && bal) atomicAdd(&s_tmp[21], __popcll(bal));
+    }
     for (int i = cnt + tid; i < n_pad; i += SEL_T) sorted[i] = 0ull;
     __syncthreads();
-
+    SEL_STAMP();
     block_bitonic_sort_desc<SEL_T>(sorted, n_pad);
+    SEL_STAMP();
 
-    // zero keys (slots the filter reserved for logits that then failed the exact threshold) sort last
-    if (tid == 0) s_tmp[21] = 0;
+    if (early) {
+        const int valid = s_tmp[21];
+        const int n_out = valid < K ? valid : K;
+        if (mine != 0ull) {
+            int rank = 0;                                  // keys greater than mine (keys are unique, the list descends)
+            for (int step = n_pad >> 1; step >= 1; step >>= 1) rank += (sorted[rank + step - 1] > mine) ? step : 0;
+            if (rank < n_out)
+                decode_store(p, l, b, mine, rank, my_r, my_an, image_hw, num_levels, cand_boxes, cand_scores, cand_labels,
+                             cand_index);
+        }
+        if (tid == 0) cand_count[b * num_levels + l] = n_out;
+#ifdef OD_SEL_STAMPS
+        SEL_STAMP();
+        __syncthreads();
+        if (tid == 0 && cand_index)
+            for (int i = 0; i < 16; ++i) cand_index[slot * K + K - 16 + i] = i < st_n ? (long long)st[i] : 0ll;
+#endif
+        return;
+    }
+    // more keys than threads: zero keys sort last
     __syncthreads();
     for (int i = tid; i < cnt; i += SEL_T)
         if (sorted[i] != 0ull && (i + 1 == n_pad || sorted[i + 1] == 0ull)) s_tmp[21] = i + 1;
     __syncthreads();
     const int valid = s_tmp[21];
     const int n_out = valid < K ? valid : K;
-    for (int r = tid; r < n_out; r += SEL_T)
-        decode_store(p, l, b, sorted[r], r, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
+    for (int r = tid; r < n_out; r += SEL_T) {
+        float4 rr, an;
+        gather_candidate(li, p.num_classes, b, sorted[r], rr, an);
+        decode_store(p, l, b, sorted[r], r, rr, an, image_hw, num_levels, cand_boxes, cand_scores, cand_labels, cand_index);
+    }
     if (tid == 0) cand_count[b * num_levels + l] = n_out;
 }
 

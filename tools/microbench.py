@@ -75,7 +75,7 @@ def main():
         hc = ws[off + 256:off + 256 + len(gts) * 128].view(torch.int64)[::16]
         res["match_counters"] = {"heavy_tiles": int((hc >> 32).sum()), "heavy_entries": int((hc & 0xffffffff).sum()),
                                  "tiles": tiles}
-    if args.what in ("all", "post", "nms", "select"):
+    if args.what in ("all", "post", "nms", "select", "select_only"):
         head = synthetic.make_head_outputs(cfg, logits=args.logits)
         cls = head["cls_logits"].to(dev)
         reg = head["bbox_regression"].to(dev)
@@ -84,6 +84,9 @@ def main():
         K = cfg.topk_candidates
         sel = lambda: kernels.select_candidates(cls_l, reg_l, anc_l, hw, cfg.score_thresh, K, _C.CODER_BOXCODER, 4.135)
         res["select"] = timed(sel)
+        if args.what == "select_only":        # builds whose select kernel stops early leave the candidates unwritten
+            print(json.dumps(res))
+            return
         A = 9
 
         def to_maps(levels, per_anchor):      # [B, g*g*A, k] -> the convolution layout [B, A*k, g, g]
