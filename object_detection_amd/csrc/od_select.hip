@@ -29,7 +29,7 @@ using namespace od;
 constexpr int ST = 256;            // filter workgroup
 constexpr int CHUNK = 8192;        // logits per filter workgroup (32 KB)
 constexpr int SEL_T = 1024;        // select workgroup
-constexpr int CAP = 8192;          // keys held in LDS by the select kernel
+constexpr int CAP = 8192;          // keys held in LDS by the select kernel (16384 measured slower: two more keys per thread in every pass)
 constexpr int HBITS = 12;
 constexpr int HBINS = 1 << HBITS;  // histogram bins per radix level
 constexpr int CSTRIDE = 64;        // one key counter per 256 bytes: atomics on one cache line serialise
@@ -744,6 +744,42 @@ __device__ __forceinline__ void stream_keys(const unsigned long long* __restrict
     }
 }
 
+// Appends the keys of keys[0, total) that satisfy `pred` to dst[*counter ...), capacity cap, in no particular order.
+// A wave reserves the slots for all keys of a batch (32 per lane) with ONE returning atomic: one per key instruction,
+// as lds_append makes, is 36 dependent round trips to a counter that sixteen waves contend for when a level leaves
+// 36 k keys (10 us of a 19 us descent).
+template <typename P>
+__device__ __forceinline__ void stream_append(const unsigned long long* __restrict__ keys, unsigned int total, P pred,
+                                              unsigned long long* dst, int* counter, int cap) {
+    constexpr int U = 16;
+    const int lane = threadIdx.x & 63;
+    const ulonglong2* kv = reinterpret_cast<const ulonglong2*>(keys);
+    const unsigned int nvec = (total + 1) >> 1;
+    for (unsigned int v0 = 0; v0 < nvec; v0 += SEL_T * U) {
+        ulonglong2 k[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned int v = v0 + u * SEL_T + threadIdx.x;
+            k[u] = v < nvec ? kv[v] : make_ulonglong2(0ull, 0ull);
+            if (2 * v + 1 >= total) k[u].y = 0ull;             // odd tail: the slot after the last key is not ours
+        }
+        int mine = 0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) mine += (pred(k[u].x) ? 1 : 0) + (pred(k[u].y) ? 1 : 0);
+        const int incl = wave_inclusive_sum(mine);
+        const int wave_total = __builtin_amdgcn_readlane(incl, 63);
+        if (wave_total == 0) continue;
+        int base = 0;
+        if (lane == 63) base = atomicAdd(counter, wave_total);
+        int pos = __builtin_amdgcn_readlane(base, 63) + incl - mine;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (pred(k[u].x)) { if (pos < cap) dst[pos] = k[u].x; ++pos; }
+            if (pred(k[u].y)) { if (pos < cap) dst[pos] = k[u].y; ++pos; }
+        }
+    }
+}
+
 // wave-aggregated append of `k` (where take) to dst[*counter ...), capacity cap
 __device__ __forceinline__ void lds_append(bool take, unsigned long long k, unsigned long long* dst, int* counter, int cap) {
     const int lane = threadIdx.x & 63;
@@ -875,7 +911,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
 #ifdef OD_SEL_STAMPS
     unsigned long long st[16];
     int st_n = 0;
-#define SEL_STAMP() do { if (st_n < 16) st[st_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SEL_STAMP() do { if (st_n < 15) st[st_n++] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define SEL_STAMP() do { } while (0)
 #endif
@@ -908,7 +944,9 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
                 if (k != 0ull && k >= lo && (k - lo) <= span) atomicAdd(&s_hist[(unsigned int)((k - lo) >> shift)], 1u);
             });
             __syncthreads();
+            SEL_STAMP();
             find_cut_bin(s_hist, nb, need, s_tmp);
+            SEL_STAMP();
             const int bstar = s_tmp[16], above = s_tmp[17], h = s_tmp[18], found = s_tmp[19];
             __syncthreads();
             if (!found) break;                     // fewer valid keys than K: everything at or above lo is taken
@@ -918,7 +956,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
             need -= above;
             if (n_ge <= CAP || w == 0) break;
         }
-            stream_keys(keys, total, [&](unsigned long long k) { lds_append(k >= lo && k != 0ull, k, s_keys, &s_tmp[20], CAP); });
+        stream_append(keys, total, [&](unsigned long long k) { return k >= lo && k != 0ull; }, s_keys, &s_tmp[20], CAP);
         __syncthreads();
         cnt = s_tmp[20];
         if (cnt > CAP) cnt = CAP;   // unreachable for unique keys; keeps LDS accesses in bounds
@@ -1036,7 +1074,7 @@ __global__ __launch_bounds__(SEL_T) void select_kernel(SelectParams p, int num_l
         SEL_STAMP();
         __syncthreads();
         if (tid == 0 && cand_index)
-            for (int i = 0; i < 16; ++i) cand_index[slot * K + K - 16 + i] = i < st_n ? (long long)st[i] : 0ll;
+            for (int i = 0; i < 16; ++i) cand_index[slot * K + K - 16 + i] = i == 15 ? (long long)total : (i < st_n ? (long long)st[i] : 0ll);
 #endif
         return;
     }
