@@ -541,18 +541,12 @@ __device__ __forceinline__ void find_cut_bin(const unsigned int* s_hist, int nb,
 
 // One workgroup per (image, level).  Levels with at least SAMPLE_MIN logits: S logits are read in runs of SAMPLE_RUN
 // at hashed positions (one run per window of E / runs logits) and the r-th best of them, r = 3*K*S/E + 32, is located
-// to 24 bits with two histogram passes.  About 3K + 32*E/S logits of the level are at least as good, so with
+// with one pass over a 4096-bin histogram.  About 3K + 32*E/S logits of the level are at least as good, so with
 // overwhelming probability at least K are -- and if not, the filter's redo pass repairs it.
 // Without centre-ness the score is a non-decreasing function of the logit (up to the last bits of the specified
 // sigmoid), so the samples are ranked by their logits and only the located bound is put through the sigmoid; with
 // centre-ness every sample is scored.  The bounds handed to the filter carry margins that cover those last bits and
 // the rounding of logf: a bound that is too low only lets more keys through.
-__device__ __forceinline__ uint32_t ordered_bits(float x) {        // monotone map of a float onto unsigned integers
-    const uint32_t u = f2u(x);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float from_ordered_bits(uint32_t k) { return u2f((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
-
 // Sample of a level: S logits in runs of SAMPLE_RUN, one run per window of E / runs logits at a hashed offset; the
 // r-th best sample is the bound.  Returns false if the level gets no bound (small level, or the bound would remove
 // little).
@@ -573,11 +567,30 @@ constexpr long long SAMPLE_IN_REGS = 2 * SEL_T * SU;           // larger samples
 constexpr int SAMPLE_PART = SEL_T * SU;                        // samples per workgroup of sample_part_kernel
 constexpr int SAMPLE_PARTS_MAX = (int)(SAMPLE_MAX / SAMPLE_PART);
 
-// rank keys (0: cannot pass the threshold) of the samples base + u * SEL_T + tid, u < NU; all NU scattered loads of a
+// Histogram bins of a sample.  Without centre-ness the samples are ranked by their logits: bin = 128 * (logit -
+// origin), origin = the prefilter bound (or -16 when every logit is scored), the last bin also takes everything
+// above origin + 32; with centre-ness by their scores: 4096 bins over (threshold, 1].  The bound that comes out is the
+// lower edge of a bin, i.e. it is located to 1/128 in the logit (0.2 % in the score) -- the margins applied to it
+// afterwards are wider, and a bound that is a little low only lets a few more keys through.
+constexpr int BIN_NONE = 0xFFFF;
+struct SampleBins { float origin, scale; };
+__device__ __forceinline__ SampleBins sample_bins(const FilterParams& p) {
+    SampleBins sb;
+    if (p.has_ctr) { sb.origin = p.thresh > 0.0f ? p.thresh : 0.0f; sb.scale = (float)HBINS / (1.0f - sb.origin); }
+    else { sb.origin = p.prefilter ? p.pre_logit : -16.0f; sb.scale = 128.0f; }
+    return sb;
+}
+__device__ __forceinline__ int bin_of(const SampleBins& sb, float v) {
+    const float t = (v - sb.origin) * sb.scale;
+    return t >= (float)(HBINS - 1) ? HBINS - 1 : (t > 0.0f ? (int)t : 0);      // NaN -> 0
+}
+__device__ __forceinline__ float bin_edge(const SampleBins& sb, int bin) { return sb.origin + (float)bin / sb.scale; }
+
+// bins (BIN_NONE: cannot pass the threshold) of the samples base + u * SEL_T + tid, u < NU; all NU scattered loads of a
 // thread are requested before the first is used
 template <int NU>
 __device__ __forceinline__ void sample_keys(const FilterParams& p, int l, int b, const float* __restrict__ src,
-                                            const SampleGeometry& g, uint32_t base, uint32_t* key) {
+                                            const SampleGeometry& g, const SampleBins& sb, uint32_t base, int* bin) {
     const int tid = threadIdx.x;
     auto position = [&](int u) -> uint32_t {
         const uint32_t i = base + u * SEL_T + tid;
@@ -587,28 +600,31 @@ __device__ __forceinline__ void sample_keys(const FilterParams& p, int l, int b,
     float x[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) x[u] = src[position(u)];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        key[u] = 0u;
-        if (p.prefilter && x[u] <= p.pre_logit) continue;
-        if (p.has_ctr) {
+    // two loops, not one with the test inside: unrolled, the centre-ness path (a dependent load and two sigmoids per
+    // sample) is hundreds of instructions per sample that the plain path would have to jump over NU times
+    if (p.has_ctr) {
+#pragma unroll 1
+        for (int u = 0; u < NU; ++u) {
+            bin[u] = BIN_NONE;
+            if (p.prefilter && x[u] <= p.pre_logit) continue;
             const float sc = score_of(p, l, b, x[u], flat_of(p, l, position(u)));
-            if (sc > p.thresh) key[u] = f2u(sc);
-        } else {
-            key[u] = ordered_bits(x[u]);
+            if (sc > p.thresh) bin[u] = bin_of(sb, sc);
         }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) bin[u] = (p.prefilter && x[u] <= p.pre_logit) ? BIN_NONE : bin_of(sb, x[u]);
     }
 }
 
-// Scratch of a large sample, in the level's own key region (free until the filter runs; S * 4 + parts * 16 KiB of
-// its E * 8 bytes): the S rank keys, then one 4096-bin histogram of their top 12 bits per part.
+// Scratch of a large sample, in the level's own key region (free until the filter runs; parts * 16 KiB of its E * 8
+// bytes): one 4096-bin histogram per part.
 __device__ __forceinline__ uint32_t* sample_stash(const FilterParams& p, unsigned long long* keys, int l, int b) {
     return reinterpret_cast<uint32_t*>(keys + (long long)b * p.keys_per_image + p.key_off[l]);
 }
 
 // Gathering a large sample is bound by the latency of its scattered loads (one batch of 16 per thread takes ~5 us,
 // and one workgroup needs S / 16384 batches): the parts of such a sample are gathered by a workgroup each, which
-// leaves the rank keys and a partial histogram for sample_kernel.
+// leaves a partial histogram for sample_kernel.
 __global__ __launch_bounds__(SEL_T) void sample_part_kernel(FilterParams p, unsigned long long* __restrict__ keys) {
     __shared__ unsigned int s_hist[HBINS];
     const int tid = threadIdx.x;
@@ -619,16 +635,14 @@ __global__ __launch_bounds__(SEL_T) void sample_part_kernel(FilterParams p, unsi
     for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
     __syncthreads();
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
-    uint32_t* stash = sample_stash(p, keys, l, b);
-    uint32_t key[SU];
-    sample_keys<SU>(p, l, b, src, g, (uint32_t)part * SAMPLE_PART, key);
+    const SampleBins sb = sample_bins(p);
+    int bin[SU];
+    sample_keys<SU>(p, l, b, src, g, sb, (uint32_t)part * SAMPLE_PART, bin);
 #pragma unroll
-    for (int u = 0; u < SU; ++u) {
-        stash[(uint32_t)part * SAMPLE_PART + u * SEL_T + tid] = key[u];
-        if (key[u]) atomicAdd(&s_hist[key[u] >> 20], 1u);
-    }
+    for (int u = 0; u < SU; ++u)
+        if (bin[u] != BIN_NONE) atomicAdd(&s_hist[bin[u]], 1u);
     __syncthreads();
-    uint32_t* hist = stash + g.S + (long long)part * HBINS;
+    uint32_t* hist = sample_stash(p, keys, l, b) + (long long)part * HBINS;
     for (int i = tid; i < HBINS; i += SEL_T) hist[i] = s_hist[i];
 }
 
@@ -650,74 +664,49 @@ __global__ __launch_bounds__(SEL_T) void sample_kernel(FilterParams p, CutInfo* 
         return;
     }
     const long long S = g.S;
-    const int r = g.r;
     const float* src = p.cls[l] + (long long)b * p.cls_stride[l];
     constexpr int U = SU;
-    const uint32_t* stash = sample_stash(p, keys, l, b);       // large samples: written by sample_part_kernel
-    // up to 32 samples per thread stay in registers for the second pass; larger samples come from the stash
-    const bool in_regs = S <= SAMPLE_IN_REGS;
-    uint32_t kreg[2 * U];
-    // pass A: the top 12 bits of the rank key
+    const SampleBins sb = sample_bins(p);
     for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
     __syncthreads();
-    if (in_regs) {
+    if (S <= SAMPLE_IN_REGS) {                                 // up to 32 samples per thread, gathered here
+        int bin[2 * U];
         if (S > SEL_T * U) {
-            sample_keys<2 * U>(p, l, b, src, g, 0u, kreg);
+            sample_keys<2 * U>(p, l, b, src, g, sb, 0u, bin);
         } else {
-            sample_keys<U>(p, l, b, src, g, 0u, kreg);
+            sample_keys<U>(p, l, b, src, g, sb, 0u, bin);
 #pragma unroll
-            for (int u = 0; u < U; ++u) kreg[U + u] = 0u;
+            for (int u = 0; u < U; ++u) bin[U + u] = BIN_NONE;
         }
 #pragma unroll
         for (int u = 0; u < 2 * U; ++u)
-            if (kreg[u]) atomicAdd(&s_hist[kreg[u] >> 20], 1u);
-    } else {
+            if (bin[u] != BIN_NONE) atomicAdd(&s_hist[bin[u]], 1u);
+    } else {                                                   // larger samples: the parts' histograms
+        const uint32_t* stash = sample_stash(p, keys, l, b);
         const int parts = (int)(S / SAMPLE_PART);
         for (int i = tid; i < HBINS; i += SEL_T) {
             unsigned int c = 0;
-            for (int q = 0; q < parts; ++q) c += stash[S + (long long)q * HBINS + i];
+            for (int q = 0; q < parts; ++q) c += stash[(long long)q * HBINS + i];
             s_hist[i] = c;
         }
     }
     __syncthreads();
-    find_cut_bin(s_hist, HBINS, r, s_tmp);
-    const int bin1 = s_tmp[16], above = s_tmp[17], found = s_tmp[19];
-    __syncthreads();
-    if (!found) {                                              // fewer than r samples can pass at all
-        if (tid == 0) cuts[(long long)b * p.num_levels + l] = out;
-        return;
-    }
-    // pass B: the next 12 bits inside that bin
-    for (int i = tid; i < HBINS; i += SEL_T) s_hist[i] = 0;
-    __syncthreads();
-    if (in_regs) {
-#pragma unroll
-        for (int u = 0; u < 2 * U; ++u)
-            if (kreg[u] && (int)(kreg[u] >> 20) == bin1) atomicAdd(&s_hist[(kreg[u] >> 8) & 0xFFFu], 1u);
-    } else {
-        for (uint32_t base = 0; base < (uint32_t)S; base += SEL_T * U) {      // S is a multiple of SEL_T * U
-            uint32_t k[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) k[u] = stash[base + u * SEL_T + tid];  // all loads of a batch in flight together
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (k[u] && (int)(k[u] >> 20) == bin1) atomicAdd(&s_hist[(k[u] >> 8) & 0xFFFu], 1u);
-        }
-    }
-    __syncthreads();
-    find_cut_bin(s_hist, HBINS, r - above, s_tmp);
-    const int bin2 = s_tmp[16];
+    find_cut_bin(s_hist, HBINS, g.r, s_tmp);
+    const int bin1 = s_tmp[16], found = s_tmp[19];
     if (tid == 0) {
-        const uint32_t edge = ((uint32_t)bin1 << 20) | ((uint32_t)bin2 << 8);     // lower edge of the located bin
-        // 0.9999: below the score of every logit >= the bound even where the specified sigmoid is not monotone
-        const float cut = p.has_ctr ? u2f(edge) : spec_sigmoidf(from_ordered_bits(edge)) * 0.9999f;
-        if (cut > p.thresh && cut < 1.0f) {
-            float c = cut * 0.996f;                            // below every true score that rounds to >= cut
-            if (p.has_ctr) c = c * c;                          // sqrt(sig(cls) * sig(ctr)) >= cut needs sig(cls) >= cut^2
-            const float lg = logf(c / (1.0f - c));
-            float pre = lg - 0.01f * (1.0f + fabsf(lg));
-            if (p.prefilter && pre < p.pre_logit) pre = p.pre_logit;
-            out.cut = cut; out.pre = pre; out.active = 1;
+        // bin 0 of the logit scale also holds everything below the origin when nothing is prefiltered: no bound then
+        if (found && (bin1 > 0 || p.has_ctr || p.prefilter)) {
+            const float edge = bin_edge(sb, bin1);             // lower edge of the located bin
+            // 0.9999: below the score of every logit >= the bound even where the specified sigmoid is not monotone
+            const float cut = p.has_ctr ? edge : spec_sigmoidf(edge) * 0.9999f;
+            if (cut > p.thresh && cut < 1.0f) {
+                float c = cut * 0.996f;                        // below every true score that rounds to >= cut
+                if (p.has_ctr) c = c * c;                      // sqrt(sig(cls) * sig(ctr)) >= cut needs sig(cls) >= cut^2
+                const float lg = logf(c / (1.0f - c));
+                float pre = lg - 0.01f * (1.0f + fabsf(lg));
+                if (p.prefilter && pre < p.pre_logit) pre = p.pre_logit;
+                out.cut = cut; out.pre = pre; out.active = 1;
+            }
         }
         cuts[(long long)b * p.num_levels + l] = out;
     }
