@@ -486,6 +486,26 @@ def test_select_ties_beyond_lds_capacity(device):
         _check_select_single_level(device, logits, C, 0.5, K)
 
 
+def test_select_tied_groups_in_lds(device):
+    """Fewer candidates than LDS holds, in groups of equal scores: a pass of the radix descent that meets keys which
+    agree in the bits it looks at skips to the highest bit that varies -- score bits when two groups differ in the last
+    bits of the score, index bits inside one group.  K inside the first group, inside the second, at a group's edge,
+    and above / below the thread count of the top-k workgroup (1024: one key per thread or several)."""
+    gen = torch.Generator().manual_seed(13)
+    N, C = 2500, 3                                       # 7500 logits
+    logits = torch.empty((2, N, C)).normal_(-2.0, 1.0, generator=gen)
+    u = torch.rand((2, N, C), generator=gen)
+    a = 3.0
+    logits[u < 0.30] = a                                 # ~2250 equal scores on top ...
+    logits[(u >= 0.30) & (u < 0.55)] = float(np.nextafter(np.float32(a), np.float32(0)))   # ... ~1900 one ulp below
+    logits[1][(u[1] >= 0.55) & (u[1] < 0.60)] = 40.0     # image 1: ~375 saturated scores above both groups
+    for K in (100, 1000, 1024, 1025, 2250, 3000, 4500):
+        _check_select_single_level(device, logits, C, 0.5, K)
+    # the same with centre-ness (scores are products, the groups stay groups)
+    ctr = torch.full((2, N, 1), 2.0)
+    _check_select_single_level(device, logits, C, 0.2, 1000, ctrness=ctr)
+
+
 def test_select_all_equal_and_no_threshold(device):
     """Every score identical (order = flat index), and score_thresh <= 0 (nothing is prefiltered)."""
     logits = torch.full((1, 5000, 2), 0.25)
