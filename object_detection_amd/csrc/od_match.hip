@@ -195,19 +195,31 @@ __device__ __forceinline__ void visit_survivors(unsigned long long mask, const f
     }
 }
 
+// The first chunk of a GT range (lane j: box g_begin + j and, with gmax, its current row maximum): requested by
+// for_each_overlapping_gt itself, or earlier by its caller so that the request travels together with the tile's anchors.
+struct GtChunk { float4 box; uint32_t max_key; };
+__device__ __forceinline__ GtChunk first_gt_chunk(const float4* __restrict__ gt, int m0, const uint32_t* gmax, int g_begin,
+                                                  int g_end) {
+    const int lane = threadIdx.x & 63;
+    GtChunk c;
+    c.box = make_float4(0.f, 0.f, 0.f, 0.f);
+    c.max_key = 0u;
+    if (g_begin + lane < g_end) {
+        c.box = gt[m0 + g_begin + lane];
+        if (gmax) c.max_key = gmax[(long long)(m0 + g_begin + lane) * GSTRIDE];
+    }
+    return c;
+}
+
 template <typename F, typename D>
 __device__ __forceinline__ void for_each_overlapping_gt(const WaveTile& t, const float4* __restrict__ gt, int m0,
                                                         const uint32_t* gmax, int g_begin, int g_end, int share,
-                                                        int nshare, F f, D chunk_done, int chunk_step = 1) {
+                                                        int nshare, F f, D chunk_done, int chunk_step, const GtChunk& head) {
     // chunk_step > 1: only every chunk_step-th 64-GT chunk, starting with the one at g_begin (waves that split a long
     // GT list by chunks instead of by rank do not repeat each other's culling)
     const int lane = threadIdx.x & 63;
-    float4 nxt = make_float4(0.f, 0.f, 0.f, 0.f);
-    uint32_t nxt_max = 0u;
-    if (g_begin + lane < g_end) {
-        nxt = gt[m0 + g_begin + lane];
-        if (gmax) nxt_max = gmax[(long long)(m0 + g_begin + lane) * GSTRIDE];
-    }
+    float4 nxt = head.box;
+    uint32_t nxt_max = head.max_key;
     int rank = 0;
     for (int g0 = g_begin; g0 < g_end; g0 += 64 * chunk_step) {
         const float4 gb = nxt;
@@ -337,7 +349,7 @@ __global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void ma
             chunk_done(64, 0u);
         }
     } else {
-        for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, chunk_done);
+        for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, chunk_done, 1, first_gt_chunk(gt, m0, nullptr, 0, M));
     }
 
 #pragma unroll
@@ -370,11 +382,19 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
     __shared__ float s_best[NW][WTILE];
     __shared__ int s_bidx[NW][WTILE];
     __shared__ int s_cost[HT];
+    __shared__ int s_tile[HT];
     __shared__ int s_pick;
     __shared__ uint32_t s_gmax[GMAX_LDS];          // row maxima of the current tile (ordered keys; 0 = no overlap)
     __shared__ uint2 s_ent[NW][ECAP];              // staged entries of each wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int b = blockIdx.x;
+#ifdef OD_HEAVY_STAMPS
+    unsigned long long hst[8];
+    hst[0] = __builtin_amdgcn_s_memrealtime();
+#define HSTAMP(i) hst[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define HSTAMP(i) do { } while (0)
+#endif
     const unsigned long long hc = ws.heavy_count[b * 16];
     const int nheavy = (int)(hc >> 32);
     const int m0 = gt_offsets[b];
@@ -388,9 +408,16 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
     // Blocks are numbered image-fastest, so the hardware hands out "the r-th tile of every image" together.
     // With r = rank by cost (GT met, descending) every CU receives a mix of expensive and cheap tiles
     // instead of whatever the arrival order of the queue gives; done when the queue fits one pass.
+    // Short GT lists: every wave culls all GT and takes every NW-th survivor (even split whatever the list looks
+    // like).  Long lists: every wave takes every NW-th chunk of 64 GT, culling included -- with 2000 GT the
+    // culling of all chunks by all waves was 40 % of the kernel's instructions.
+    const bool by_chunk = M > 64 * NW * 2;
     const bool by_cost = nheavy <= HT;
-    if (by_cost) {
-        s_cost[threadIdx.x] = (int)threadIdx.x < nheavy ? ws.heavy_queue[(long long)b * wtiles + threadIdx.x].z : -1;
+    if (by_cost) {                                   // the queue in LDS: picking a tile costs no further memory round trip
+        int4 q = make_int4(0, 0, -1, 0);
+        if ((int)threadIdx.x < nheavy) q = ws.heavy_queue[(long long)b * wtiles + threadIdx.x];
+        s_cost[threadIdx.x] = q.z;
+        s_tile[threadIdx.x] = q.x;
         __syncthreads();
     }
     for (int item = blockIdx.y; item < nheavy; item += gridDim.y) {
@@ -408,14 +435,20 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
             __syncthreads();
             pick = s_pick;
         }
-        const int4 qi = ws.heavy_queue[(long long)b * wtiles + pick];
-        const int wt = qi.x;
+        HSTAMP(1);
+        const int wt = by_cost ? s_tile[pick] : ws.heavy_queue[(long long)b * wtiles + pick].x;
         const long long wslot = (long long)b * wtiles + wt;
         long long first[R];
         tile_runs(layout, wt, first);
         long long* out = matched + (long long)b * n;
+        // the wave's first GT chunk does not depend on the tile: requested before the anchors, whose bounding box
+        // (a wave reduction) would otherwise have to be complete before the request is made
+        const uint32_t* gmax_global = (want_restore && !lds_max) ? ws.gt_max_key : nullptr;
+        const int g_first = by_chunk ? 64 * wave : 0;
+        const GtChunk head = first_gt_chunk(gt, m0, gmax_global, g_first, M);
         WaveTile t;
         load_wave_tile(t, anchors + (long long)b * anchor_batch_stride, first, n);
+        HSTAMP(2);
         float best[R];
         int bidx[R];
 #pragma unroll
@@ -440,12 +473,7 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
             }
             staged = 0;
         };
-        // Short GT lists: every wave culls all GT and takes every NW-th survivor (even split whatever the list looks
-        // like).  Long lists: every wave takes every NW-th chunk of 64 GT, culling included -- with 2000 GT the
-        // culling of all chunks by all waves was 40 % of the kernel's instructions.
-        const bool by_chunk = M > 64 * NW * 2;
-        for_each_overlapping_gt(t, gt, m0, (want_restore && !lds_max) ? ws.gt_max_key : nullptr, by_chunk ? 64 * wave : 0, M,
-                                by_chunk ? 0 : wave, by_chunk ? 1 : NW,
+        for_each_overlapping_gt(t, gt, m0, gmax_global, g_first, M, by_chunk ? 0 : wave, by_chunk ? 1 : NW,
             [&](int g, int j, int, float gx1, float gy1, float gx2, float gy2, float ga) {
                 const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
                 if (want_restore && k > kZeroKey) {    // wave-uniform: this GT overlaps an anchor of the tile
@@ -462,11 +490,14 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
                     atomicMax(&ws.gt_max_key[(long long)(m0 + g0 + lane) * GSTRIDE], kreg);
                 }
                 kreg = 0u;
-            }, by_chunk ? NW : 1);
+            }, by_chunk ? NW : 1, head);
+        HSTAMP(3);
         flush_entries();
+        HSTAMP(4);
 #pragma unroll
         for (int r = 0; r < R; ++r) { s_best[wave][r * 64 + lane] = best[r]; s_bidx[wave][r * 64 + lane] = bidx[r]; }
         __syncthreads();
+        HSTAMP(5);
         if (lds_max) {                                // merge the tile's row maxima into the global ones
             for (int g = threadIdx.x; g < M; g += HT) {
                 const uint32_t v = s_gmax[g];
@@ -496,6 +527,11 @@ __global__ __launch_bounds__(HT) __attribute__((amdgpu_waves_per_eu(5))) void ma
             }
         }
         __syncthreads();
+#ifdef OD_HEAVY_STAMPS
+        HSTAMP(6);
+        if (threadIdx.x == 0 && first[0] + 8 <= n)
+            for (int i = 0; i < 7; ++i) out[first[0] + i] = (long long)(hst[i] - hst[0]) + (1ll << 40) * (i + 1);
+#endif
     }
 }
 
@@ -538,7 +574,7 @@ __device__ __forceinline__ void recheck_segment(const float4* __restrict__ ancho
                 restore[r] = restore[r] || (v == gmax);
             }
         },
-        [&](int, uint32_t) {});
+        [&](int, uint32_t) {}, 1, first_gt_chunk(gt, m0, nullptr, g_begin, g_end));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         const long long idx = first[r] + lane;
