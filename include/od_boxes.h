@@ -228,6 +228,28 @@ int od_pack_detections(const float* boxes, const float* scores, const int64_t* l
                        int32_t batch, int32_t max_det, float* message, void* stream);
 
 /*
+ * Tail of the reference's prediction loop for a whole batch in one launch.  Replaces, per image, the sequence at
+ * reference predict.py:70-76: `boxes.mul_(ratio)` (ratio = [w/width, h/height, w/width, h/height] as fp32),
+ * `nms(boxes, scores, 0.3)` (torchvision.ops.nms, class-agnostic, on the rescaled boxes), `boxes.to(torch.int32)`
+ * and the three gathers `boxes[keep]`, `scores[keep]`, `labels[keep]`.
+ *   boxes fp32 [batch, max_det, 4], scores fp32 [batch, max_det], labels int64 [batch, max_det], counts int32 [batch]:
+ *     the padded detections as od_batched_nms writes them (any score order is accepted; the greedy order is the
+ *     stable descending one, as torchvision's kernel sorts);  ratio fp32 [batch, 4] (device), 16-byte aligned
+ *   mode: 0 = threshold rule of torchvision's CPU kernel, OD_NMS_THRESHOLD_FLOAT = of its CUDA kernel
+ *   scaled_boxes fp32 [batch, max_det, 4] or NULL: the rescaled boxes of the valid detections in their given order
+ *     (what mul_ leaves in the prediction dictionary); may be the same memory as `boxes`
+ *   out_boxes int32 [batch, max_det, 4] (fp32 -> int32 conversion truncates towards zero like Tensor.to; values
+ *     outside the int32 range saturate, NaN becomes 0), out_scores fp32, out_labels int64, keep_idx int64 or NULL
+ *     (positions inside the image's detection list, as nms returns them), out_count int32 [batch].
+ *   Rows past out_count are zero-filled.  Limit: max_det <= 1024 (OD_ERR_LIMIT beyond).
+ */
+#define OD_MAX_PREDICT_TAIL 1024
+int od_predict_tail(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
+                    const float* ratio, int32_t batch, int32_t max_det, double iou_threshold, int32_t mode,
+                    float* scaled_boxes, int32_t* out_boxes, float* out_scores, int64_t* out_labels,
+                    int64_t* keep_idx, int32_t* out_count, void* stream);
+
+/*
  * Classification loss of the RetinaNet head, fused with its target construction.  Replaces torchvision
  * RetinaNetClassificationHead.compute_loss = per image sigmoid_focal_loss(logits[valid], target[valid], "sum")
  * / max(1, #foreground), averaged over the batch (head built at reference retinanet_model.py:47-54, loss taken at
@@ -361,7 +383,8 @@ int od_preprocess_images(const float* const* images, const int32_t* image_h, con
 #define OD_KERNEL_FILTER_REDO 18    /* od_select_candidates: second filter pass (normally exits at once) */
 #define OD_KERNEL_PACK 19           /* od_pack_detections */
 #define OD_KERNEL_NMS_ORDER 20      /* od_batched_nms: global order of unsorted candidates */
-#define OD_KERNEL_COUNT 21
+#define OD_KERNEL_PREDICT_TAIL 21   /* od_predict_tail */
+#define OD_KERNEL_COUNT 22
 int od_profile_select(int32_t kernel_id);
 /* Time only every `every`-th launch of a selected kernel (default 1): a timed launch costs the host tens of
  * microseconds, which a throughput measurement should not pay on every step. */

@@ -19,6 +19,7 @@ OD_MAX_BASE_ANCHORS = 16
 OD_MAX_TOPK = 8192
 OD_MAX_NMS_BOXES = 65536
 OD_NMS_NOALLOC_SCRATCH_BYTES = 8 << 20
+OD_MAX_PREDICT_TAIL = 1024
 CODER_BOXCODER, CODER_LINEAR = 0, 1
 NMS_TRICK, NMS_VANILLA, NMS_AUTO_CPU, NMS_AUTO_GPU = 0, 1, 2, 3
 NMS_THRESHOLD_FLOAT = 0x100     # or-ed into the mode: compare the fp32 IoU with float(threshold), as torchvision's CUDA kernel
@@ -55,6 +56,7 @@ SIGNATURES = {
     "od_batched_nms_noalloc": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                          _P, _P, _P, _P, _P, _P]),
     "od_pack_detections": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P]),
+    "od_predict_tail": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "od_focal_loss_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "od_focal_loss_forward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,
                                         c_int32, _P, _P, _P, _P, c_size_t, _P]),
@@ -78,7 +80,7 @@ SIGNATURES = {
 PROFILE_OFF, PROFILE_ALL = -1, -2
 KERNEL_NAMES = ["anchor", "match_assign", "match_restore", "match_fcos", "box_iou", "matcher", "decode", "filter",
                 "select", "nms", "match_heavy", "match_init", "focal_fwd", "focal_bwd", "box_loss_fwd", "box_loss_bwd", "preprocess", "sample", "filter_redo",
-                "pack", "nms_order"]
+                "pack", "nms_order", "predict_tail"]
 BOX_LOSS_L1, BOX_LOSS_SMOOTH_L1, BOX_LOSS_GIOU = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 LOSS_NORM_PER_IMAGE, LOSS_NORM_BATCH = 0, 1

@@ -697,6 +697,167 @@ __global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ bo
     if (k == 0) row[6ll * max_det] = (float)counts[b];
 }
 
+// ---- tail of the reference's prediction loop (object_detection/predict.py:70-76) for a whole batch -----------
+// Per image: boxes.mul_(ratio); keep = nms(boxes, scores, thr); boxes.to(int32)[keep], scores[keep], labels[keep].
+// One 1024-thread workgroup per image, at most PT_MAX detections (what postprocess_detections leaves: <= 1024).
+//   1. every thread scales one box and finds its place in the stable descending score order (detections arrive
+//      sorted from batched_nms, which one neighbour comparison per thread confirms; otherwise every thread counts
+//      the keys above its own);
+//   2. suppression bits: a wave takes a tile of 64 rows x 64 columns of the upper triangle, lane = column, and
+//      turns the 64 decisions "row i suppresses column j" into one 64-bit word per row with a ballot;
+//   3. one wave walks the blocks of 64 in order: a block's alive mask is what earlier kept rows left of it, the
+//      greedy choice inside the block is a scalar loop over its set bits, and the words of the newly kept rows are
+//      or-ed into the masks of the later blocks; kept detections are written in order as they are found.
+constexpr int PT_MAX = 1024;
+constexpr int PT_NB = PT_MAX / 64;
+constexpr int PT_WORDS = 64 * (PT_NB * (PT_NB + 1) / 2);     // words of the upper block triangle
+
+// first word of row block R (rows 64R .. 64R+63 hold the words of column blocks R .. PT_NB-1)
+__device__ __forceinline__ int pt_block_base(int R) { return 64 * (PT_NB * R - R * (R - 1) / 2); }
+
+struct PredictTailArgs {
+    const float4* boxes;        // [batch, max_det]
+    const float* scores;
+    const long long* labels;
+    const int* counts;
+    const float4* ratio;        // [batch]: factors of x1, y1, x2, y2
+    int max_det;
+    float thr_up;
+    float4* scaled_boxes;       // may alias boxes; may be null
+    int4* out_boxes;
+    float* out_scores;
+    long long* out_labels;
+    long long* keep_idx;        // may be null
+    int* out_count;
+};
+
+__global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
+    __shared__ __attribute__((aligned(16))) float4 s_box[PT_MAX];   // scaled boxes in score order
+    __shared__ float s_area[PT_MAX];
+    __shared__ float s_score[PT_MAX];                               // scores as given
+    __shared__ int s_src[PT_MAX];                                   // index as given of the r-th best
+    __shared__ unsigned long long s_mask[PT_WORDS];
+    __shared__ int s_nk;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const long long base = (long long)b * a.max_det;
+    int n = a.counts[b];
+    n = n < 0 ? 0 : (n > a.max_det ? a.max_det : n);
+
+    // ---- 1. scale, order ------------------------------------------------------------------------------------
+    float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+    float sc = 0.0f;
+    if (tid < n) {
+        const float4 r = a.ratio[b];
+        const float4 raw = a.boxes[base + tid];
+        bx = make_float4(raw.x * r.x, raw.y * r.y, raw.z * r.z, raw.w * r.w);
+        sc = a.scores[base + tid];
+        s_score[tid] = sc;
+        if (a.scaled_boxes) a.scaled_boxes[base + tid] = bx;
+    }
+    __syncthreads();
+    const bool in_place = !(tid > 0 && tid < n) || s_score[tid - 1] >= sc;
+    int rank = tid;
+    if (!__syncthreads_and(in_place)) {
+        const unsigned long long mine = nms_key(sc, tid);
+        rank = 0;
+        for (int j = 0; j < n; ++j) rank += nms_key(s_score[j], j) > mine ? 1 : 0;
+    }
+    if (tid < n) {
+        s_box[rank] = bx;
+        s_area[rank] = (bx.z - bx.x) * (bx.w - bx.y);
+        s_src[rank] = tid;
+    }
+    if (tid == 0) s_nk = 0;
+    __syncthreads();
+
+    // ---- 2. suppression words of the upper triangle ----------------------------------------------------------
+    ThrBand thr;
+    thr.up = a.thr_up;
+    thr.lo = a.thr_up * (1.0f - 1e-5f);
+    thr.hi = a.thr_up * (1.0f + 1e-5f);
+    thr.usable = (a.thr_up > 1e-30f) && (a.thr_up < 1e30f);
+    const int nb = (n + 63) >> 6;
+    const int tiles = nb * (nb + 1) / 2;
+    for (int t = wave; t < tiles; t += NT / 64) {
+        int R = 0, rest = t;                       // tile t -> (row block R, column block w), R <= w < nb
+        while (rest >= nb - R) { rest -= nb - R; ++R; }
+        const int w = R + rest;
+        const int j = 64 * w + lane;
+        const bool jv = j < n;
+        const float4 cj = s_box[jv ? j : 0];
+        const float aj = s_area[jv ? j : 0];
+        const int rows = (n - 64 * R) < 64 ? (n - 64 * R) : 64;
+        unsigned long long* out = s_mask + pt_block_base(R) + rest;
+        const int pitch = PT_NB - R;
+        for (int r = 0; r < rows; ++r) {
+            const int i = 64 * R + r;
+            const float4 bi = s_box[i];
+            const float ai = s_area[i];
+            const float inter = intersection(bi, cj);
+            const bool sup = over_threshold(inter, ai, aj, thr) && jv && j > i;
+            const unsigned long long word = __ballot(sup);
+            if (lane == 0) out[r * pitch] = word;
+        }
+    }
+    __syncthreads();
+
+    // ---- 3. greedy walk over the blocks (one wave) -----------------------------------------------------------
+    if (wave == 0) {
+        unsigned long long pending = 0;            // lane w: suppression bits that kept rows left on block w
+        int nk = 0;
+        for (int c = 0; c < nb; ++c) {
+            const int left = n - 64 * c;
+            const unsigned long long valid = left >= 64 ? ~0ull : ((1ull << left) - 1ull);
+            const uint32_t plo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)pending, c);
+            const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pending >> 32), c);
+            unsigned long long alive = valid & ~(((unsigned long long)phi << 32) | plo);
+            const int i = 64 * c + lane;
+            const int pitch = PT_NB - c;
+            const unsigned long long* row = s_mask + pt_block_base(c) + lane * pitch;
+            const bool iv = i < n;
+            const unsigned long long diag = iv ? row[0] : 0ull;
+            unsigned long long kept = 0, rem = alive;
+            while (rem) {
+                const int r = __builtin_ctzll(rem);
+                kept |= 1ull << r;
+                const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, r);
+                const uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(diag >> 32), r);
+                alive &= ~(((unsigned long long)dhi << 32) | dlo);
+                rem = alive & ~((2ull << r) - 1ull);
+            }
+            const bool mine = (kept >> lane) & 1ull;
+            for (int w = c + 1; w < nb; ++w) {     // what the newly kept rows suppress in later blocks
+                const unsigned long long v = mine ? row[w - c] : 0ull;
+                if (__ballot(v != 0ull) == 0ull) continue;
+                const unsigned long long all = ((unsigned long long)wave_or_all((uint32_t)(v >> 32)) << 32) |
+                                               wave_or_all((uint32_t)v);
+                if (lane == w) pending |= all;
+            }
+            if (mine) {
+                const int pos = nk + mbcnt(kept);
+                const int src = s_src[i];
+                const float4 k = s_box[i];
+                a.out_boxes[base + pos] = make_int4((int)k.x, (int)k.y, (int)k.z, (int)k.w);
+                a.out_scores[base + pos] = s_score[src];
+                a.out_labels[base + pos] = a.labels[base + src];
+                if (a.keep_idx) a.keep_idx[base + pos] = src;
+            }
+            nk += __popcll(kept);
+        }
+        if (lane == 0) { s_nk = nk; a.out_count[b] = nk; }
+    }
+    __syncthreads();
+    // ---- 4. rows past the count are zero ----------------------------------------------------------------------
+    for (int k = s_nk + tid; k < a.max_det; k += NT) {
+        a.out_boxes[base + k] = make_int4(0, 0, 0, 0);
+        a.out_scores[base + k] = 0.0f;
+        a.out_labels[base + k] = 0;
+        if (a.keep_idx) a.keep_idx[base + k] = 0;
+    }
+}
+
 }  // namespace
 
 static size_t nms_align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -708,6 +869,17 @@ extern "C" size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg,
     if (n > MAXN || num_seg > MAX_SEG) return 0;
     const size_t part = nms_align256((size_t)batch * (size_t)n * sizeof(int));
     return 3 * part + nms_align256((size_t)batch * 256);
+}
+
+// Threshold rule folded into one float: a pair is suppressed when ovr >= the returned value.
+//   torchvision's CPU kernel (default):  (double)ovr > thr   <=>  ovr >= smallest float whose double value exceeds thr
+//   torchvision's CUDA kernel (OD_NMS_THRESHOLD_FLOAT):  ovr > (float)thr  <=>  ovr >= the float after (float)thr
+static float fold_threshold(double iou_threshold, int rule) {
+    float f = (float)iou_threshold;
+    if (rule & OD_NMS_THRESHOLD_FLOAT) f = __builtin_nextafterf(f, __builtin_inff());
+    else if (!((double)f > iou_threshold)) f = __builtin_nextafterf(f, __builtin_inff());
+    if (iou_threshold != iou_threshold) f = __builtin_nanf("");   // NaN threshold: nothing suppresses
+    return f;
 }
 
 static int batched_nms_launch(const float* boxes, const float* scores, const int32_t* labels,
@@ -735,14 +907,7 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
     a.seg_stride = seg_stride;
     a.n_slots = num_seg * seg_stride;
     a.lazy = (segments_sorted && num_seg <= WSEG) ? 1 : 0;
-    // Threshold rule folded into one float: a pair is suppressed when ovr >= thr_up.
-    //   torchvision's CPU kernel (default):  (double)ovr > thr   <=>  ovr >= smallest float whose double value exceeds thr
-    //   torchvision's CUDA kernel (OD_NMS_THRESHOLD_FLOAT):  ovr > (float)thr  <=>  ovr >= the float after (float)thr
-    float f = (float)iou_threshold;
-    if (rule & OD_NMS_THRESHOLD_FLOAT) f = __builtin_nextafterf(f, __builtin_inff());
-    else if (!((double)f > iou_threshold)) f = __builtin_nextafterf(f, __builtin_inff());
-    if (iou_threshold != iou_threshold) f = __builtin_nanf("");   // NaN threshold: nothing suppresses
-    a.thr_up = f;
+    a.thr_up = fold_threshold(iou_threshold, rule);
     a.can_skip_zero = (iou_threshold >= 0.0) ? 1 : 0;
     a.mode = base_mode;
     a.max_keep = max_keep;
@@ -838,5 +1003,39 @@ extern "C" int od_pack_detections(const float* boxes, const float* scores, const
     const unsigned gx = (unsigned)((max_det + 255) / 256);
     OD_LAUNCH_KERNEL(OD_KERNEL_PACK, pack_kernel, dim3(gx > 0 ? gx : 1u, (unsigned)batch), dim3(256), 0,
                      (hipStream_t)stream, (const float4*)boxes, scores, (const long long*)labels, counts, max_det, message);
+    return OD_OK;
+}
+
+extern "C" int od_predict_tail(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
+                               const float* ratio, int32_t batch, int32_t max_det, double iou_threshold, int32_t mode,
+                               float* scaled_boxes, int32_t* out_boxes, float* out_scores, int64_t* out_labels,
+                               int64_t* keep_idx, int32_t* out_count, void* stream) {
+    if (batch < 0 || max_det < 0) return OD_ERR_ARG;
+    if (batch == 0) return OD_OK;
+    if (!counts || !out_count) return OD_ERR_ARG;
+    if (mode & ~OD_NMS_THRESHOLD_FLOAT) return OD_ERR_ARG;
+    if (max_det > PT_MAX || batch > 65535) return OD_ERR_LIMIT;
+    if (max_det == 0) {
+        OD_HIP(hipMemsetAsync(out_count, 0, sizeof(int) * (size_t)batch, (hipStream_t)stream));
+        return OD_OK;
+    }
+    if (!boxes || !scores || !labels || !ratio || !out_boxes || !out_scores || !out_labels) return OD_ERR_ARG;
+    if (((uintptr_t)boxes & 15) || ((uintptr_t)ratio & 15) || ((uintptr_t)out_boxes & 15) ||
+        ((uintptr_t)scaled_boxes & 15)) return OD_ERR_ARG;
+    PredictTailArgs a;
+    a.boxes = (const float4*)boxes;
+    a.scores = scores;
+    a.labels = (const long long*)labels;
+    a.counts = counts;
+    a.ratio = (const float4*)ratio;
+    a.max_det = max_det;
+    a.thr_up = fold_threshold(iou_threshold, mode);
+    a.scaled_boxes = (float4*)scaled_boxes;
+    a.out_boxes = (int4*)out_boxes;
+    a.out_scores = out_scores;
+    a.out_labels = (long long*)out_labels;
+    a.keep_idx = (long long*)keep_idx;
+    a.out_count = out_count;
+    OD_LAUNCH_KERNEL(OD_KERNEL_PREDICT_TAIL, predict_tail_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
     return OD_OK;
 }

@@ -478,6 +478,45 @@ def pack_detections(boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tenso
     return out
 
 
+def predict_tail(boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tensor, ratio: Tensor, iou_threshold: float,
+                 mode: int = _C.NMS_THRESHOLD_FLOAT, scale_in_place: bool = True, want_keep_idx: bool = True):
+    """Rescale + class-agnostic NMS + int32 conversion + gathers of the reference's prediction loop
+    (``object_detection/predict.py:70-76``) for a padded batch in one launch.
+
+    boxes [B, D, 4] fp32, scores [B, D] fp32, labels [B, D] int64, counts [B] int32 (the padded outputs of
+    ``batched_nms_padded``), ratio [B, 4] fp32 on the same device.  With ``scale_in_place`` the valid rows of ``boxes``
+    are overwritten with the rescaled boxes, as ``boxes.mul_(ratio)`` does.  Returns (keep_idx [B, D] int64 or None,
+    boxes int32 [B, D, 4], scores [B, D], labels [B, D], counts int32 [B]); rows past a count are zero."""
+    _require_gpu(boxes, "boxes")
+    dev = boxes.device
+    B, D = int(boxes.shape[0]), int(boxes.shape[1])
+    if tuple(boxes.shape) != (B, D, 4) or tuple(scores.shape) != (B, D) or tuple(labels.shape) != (B, D) \
+            or tuple(counts.shape) != (B,) or tuple(ratio.shape) != (B, 4):
+        raise ValueError(f"predict_tail: inconsistent shapes {tuple(boxes.shape)}, {tuple(scores.shape)}, "
+                         f"{tuple(labels.shape)}, {tuple(counts.shape)}, {tuple(ratio.shape)}")
+    if boxes.dtype != torch.float32 or scores.dtype != torch.float32 or labels.dtype != torch.int64 \
+            or counts.dtype != torch.int32 or ratio.dtype != torch.float32:
+        raise TypeError("predict_tail: boxes / scores / ratio must be fp32, labels int64 and counts int32")
+    for name, t in (("boxes", boxes), ("scores", scores), ("labels", labels), ("counts", counts), ("ratio", ratio)):
+        if t.device != dev:
+            raise RuntimeError(f"predict_tail: {name} is on {t.device}, boxes on {dev}")
+        if not t.is_contiguous():
+            raise ValueError(f"predict_tail: {name} must be contiguous")
+    if D > _C.OD_MAX_PREDICT_TAIL:
+        raise _C.OdBoxesError(f"od_predict_tail: {D} detections per image exceed the limit of {_C.OD_MAX_PREDICT_TAIL}")
+    keep_idx = torch.empty((B, D), dtype=torch.int64, device=dev) if want_keep_idx else None
+    out_boxes = torch.empty((B, D, 4), dtype=torch.int32, device=dev)
+    out_scores = torch.empty((B, D), dtype=torch.float32, device=dev)
+    out_labels = torch.empty((B, D), dtype=torch.int64, device=dev)
+    out_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    rc = _C.lib().od_predict_tail(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _ptr(ratio), B, D,
+                                  float(iou_threshold), int(mode), _ptr(boxes if scale_in_place else None),
+                                  _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels), _ptr(keep_idx), _ptr(out_count),
+                                  _stream(dev))
+    _C.check(rc, "od_predict_tail")
+    return keep_idx, out_boxes, out_scores, out_labels, out_count
+
+
 # ------------------------------------------------------------------------------------------------
 _DTYPE_CODES = {torch.float32: _C.DTYPE_F32, torch.float16: _C.DTYPE_F16, torch.bfloat16: _C.DTYPE_BF16}
 

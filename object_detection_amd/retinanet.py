@@ -147,10 +147,10 @@ class _PendingBatch:
     """Padded NMS outputs of a batch and the detection counts on their way to the host (asynchronous copy into a row of
     pinned memory + an event recorded behind it).  ``counts()`` waits for that event once.  The pinned rows are handed
     out in turn; a row whose previous batch was never looked at is read out (one wait) before it is reused."""
-    __slots__ = ("boxes", "scores", "labels", "counts_host", "event", "_counts", "_rows", "__weakref__")
+    __slots__ = ("boxes", "scores", "labels", "counts_dev", "counts_host", "event", "_counts", "_rows", "__weakref__")
 
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
-        self.boxes, self.scores, self.labels = boxes, scores, labels
+        self.boxes, self.scores, self.labels, self.counts_dev = boxes, scores, labels, counts_dev
         B = int(counts_dev.shape[0])
         pool = _count_pool.get(B)
         if pool is None:

@@ -740,3 +740,22 @@ def fcos_postprocess(head_outputs: Dict[str, List[Tensor]], anchors: List[List[T
             det.update(keep=keep, cand_boxes=image_boxes, cand_scores=image_scores, cand_labels=image_labels)
         detections.append(det)
     return detections
+
+
+# --------------------------------------------------------------------------------------------
+# reference object_detection/predict.py:63-76 -- what the prediction loop does with one image's detections
+# --------------------------------------------------------------------------------------------
+def predict_tail(prediction: Dict[str, Tensor], image_wh: Tuple[int, int], model_wh: Tuple[int, int],
+                 iou_threshold: float = 0.3, float_rule: bool = False):
+    """Restatement of reference ``object_detection/predict.py:66-76`` for one image: ``ratio = torch.tensor([w / width,
+    h / height] * 2)`` (Python doubles rounded to fp32), ``boxes.mul_(ratio)`` (in place: the prediction dictionary
+    keeps the rescaled boxes), ``nms(boxes, scores, 0.3)``, ``boxes.to(torch.int32)`` and the gathers by the kept
+    indices.  Returns (boxes int32 [k, 4], scores [k], labels [k], keep [k])."""
+    w, h = image_wh
+    width, height = model_wh
+    boxes, scores, labels = prediction["boxes"], prediction["scores"], prediction["labels"]
+    ratio = torch.tensor([w / width, h / height] * 2)
+    boxes.mul_(ratio)
+    nms_indices = nms(boxes, scores, iou_threshold, float_rule)
+    boxes = boxes.to(torch.int32)
+    return boxes[nms_indices], scores[nms_indices], labels[nms_indices], nms_indices

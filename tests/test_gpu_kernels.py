@@ -871,3 +871,83 @@ def test_select_very_large_level_deferred_reservation(device):
     keys_bytes = (((E + 31) & ~31) * 8 + 255) & ~255
     counters = ws[keys_bytes:keys_bytes + 3 * 256].view(torch.int32).cpu()
     assert 0 < int(counters[64]) < 1000 and int(counters[128]) >= S, counters[[0, 64, 128]].tolist()
+
+
+def _predict_tail_checkers(boxes, scores, labels, image_wh, model_wh, thr, float_rule):
+    """Both restatements of reference predict.py:66-76 for one image; returns the torch one after checking that the
+    scalar C route (fp32 products in numpy, orc_nms, truncation) gives the same answer."""
+    pred = {"boxes": boxes.clone(), "scores": scores.clone(), "labels": labels.clone()}
+    tb, ts, tl, tk = tv.predict_tail(pred, image_wh, model_wh, thr, float_rule)
+    ratio = np.array([image_wh[0] / model_wh[0], image_wh[1] / model_wh[1]] * 2, dtype=np.float32)
+    scaled = boxes.numpy() * ratio
+    ck = c_oracle.nms(scaled, scores.numpy(), thr, float_rule)
+    assert np.array_equal(ck, tk.numpy())
+    assert np.array_equal(np.trunc(scaled[ck]).astype(np.int32), tb.numpy())
+    assert np.array_equal(scaled, pred["boxes"].numpy())          # mul_ left the rescaled boxes in the dictionary
+    return tb, ts, tl, tk, pred["boxes"]
+
+
+@pytest.mark.parametrize("batch,max_det,extent,sorted_scores", [
+    (16, 500, 700.0, True),      # the benchmark's detections_per_img
+    (3, 300, 150.0, True),       # the reference's default (configs/config_all.py:12), dense: many suppressions
+    (4, 1024, 900.0, False),     # the limit, scores in arbitrary order with ties
+    (2, 65, 60.0, False),
+    (1, 1, 10.0, True),
+])
+def test_predict_tail_matches_reference_loop(device, batch, max_det, extent, sorted_scores):
+    gen = torch.Generator().manual_seed(batch * 1000 + max_det)
+    model_wh = (1024, 1024)
+    counts = torch.randint(max_det // 2, max_det + 1, (batch,), generator=gen, dtype=torch.int32)
+    counts[0] = max_det
+    if batch > 1:
+        counts[batch - 1] = 0
+    boxes = torch.stack([_random_boxes(max_det, gen, extent) for _ in range(batch)])
+    scores = torch.rand((batch, max_det), generator=gen)
+    scores[:, ::7] = 0.75
+    if sorted_scores:
+        scores = scores.sort(dim=1, descending=True, stable=True)[0]
+    labels = torch.randint(1, 4, (batch, max_det), generator=gen)
+    sizes = [(int(640 + 37 * i), int(480 + 101 * i)) for i in range(batch)]          # (w, h) per image
+    ratio = torch.tensor([[w / model_wh[0], h / model_wh[1]] * 2 for w, h in sizes], dtype=torch.float32)
+    for thr, mode, float_rule in ((0.3, _C.NMS_THRESHOLD_FLOAT, True), (0.5, 0, False)):
+        dboxes = boxes.to(device)
+        keep, ob, os_, ol, oc = kernels.predict_tail(dboxes, scores.to(device), labels.to(device), counts.to(device),
+                                                     ratio.to(device), thr, mode, scale_in_place=True)
+        assert ob.dtype == torch.int32
+        for i in range(batch):
+            c = int(counts[i])
+            tb, ts, tl, tk, scaled = _predict_tail_checkers(boxes[i, :c], scores[i, :c], labels[i, :c], sizes[i],
+                                                            model_wh, thr, float_rule)
+            k = int(oc[i].item())
+            assert k == tk.numel(), (i, thr, k, tk.numel())
+            assert torch.equal(keep[i, :k].cpu(), tk)
+            assert torch.equal(ob[i, :k].cpu(), tb)
+            assert torch.equal(os_[i, :k].cpu(), ts)
+            assert torch.equal(ol[i, :k].cpu(), tl)
+            assert torch.equal(dboxes[i, :c].cpu(), scaled)                      # rescaled in place, bit for bit
+            assert torch.equal(dboxes[i, c:].cpu(), boxes[i, c:])                # rows past the count untouched
+            assert not ob[i, k:].any() and not os_[i, k:].any() and not ol[i, k:].any()
+
+
+def test_predict_tail_known_answers_and_limits(device):
+    # IoU == float(0.3) exactly: [0,0,10,10] vs [0,0,10,3]: inter 30, union 100 -> fp32 quotient == float(0.3), which is
+    # above the double 0.3 (CPU rule suppresses) and not above float(0.3) (CUDA rule keeps); the ratio 0.5 keeps IoU
+    b = torch.tensor([[[0., 0., 20., 20.], [0., 0., 20., 6.], [40., 40., 61., 61.]]], device=device)
+    s = torch.tensor([[0.9, 0.8, 0.7]], device=device)
+    l = torch.tensor([[1, 2, 3]], device=device)
+    c = torch.tensor([3], dtype=torch.int32, device=device)
+    r = torch.full((1, 4), 0.5, device=device)
+    keep, ob, _, ol, oc = kernels.predict_tail(b.clone(), s, l, c, r, 0.3, 0)
+    assert int(oc.item()) == 2 and keep[0, :2].tolist() == [0, 2] and ol[0, :2].tolist() == [1, 3]
+    assert ob[0, :2].tolist() == [[0, 0, 10, 10], [20, 20, 30, 30]]             # 30.5 truncates to 30
+    keep, _, _, _, oc = kernels.predict_tail(b.clone(), s, l, c, r, 0.3, _C.NMS_THRESHOLD_FLOAT)
+    assert int(oc.item()) == 3 and keep[0, :3].tolist() == [0, 1, 2]
+    # negative coordinates truncate towards zero; a degenerate pair (0/0) never suppresses
+    b2 = torch.tensor([[[-3.7, -0.2, 5.9, 7.99], [1., 1., 1., 1.], [1., 1., 1., 1.]]], device=device)
+    keep, ob, _, _, oc = kernels.predict_tail(b2, s, l, c, torch.ones((1, 4), device=device), 0.3, 0,
+                                              scale_in_place=False)
+    assert int(oc.item()) == 3 and ob[0, 0].tolist() == [-3, 0, 5, 7]
+    with pytest.raises(_C.OdBoxesError):
+        n = _C.OD_MAX_PREDICT_TAIL + 1
+        kernels.predict_tail(torch.zeros((1, n, 4), device=device), torch.zeros((1, n), device=device),
+                             torch.zeros((1, n), dtype=torch.int64, device=device), c[:1], r, 0.3)

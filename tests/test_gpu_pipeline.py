@@ -748,3 +748,43 @@ def test_fused_losses_take_autocast_head_outputs(device, dtype):
         spacing = 2.0 ** -24 if dtype is torch.float16 else 0.0      # fp16 subnormal spacing (no loss scaling here)
         tol = 1e-5 * w.abs().max() + ulp * w.abs() + spacing
         assert bool(((g - w).abs() <= tol).all()), float((g - w).abs().max())
+
+
+def test_prediction_loop_tail_on_model_detections(device):
+    """predict.rescale_nms on the list postprocess_detections returns (padded tensors used where they are, nobody
+    waits for the counts) and on materialised dictionaries, against the restatement of reference predict.py:66-76 run
+    image by image on the same detections."""
+    from object_detection_amd import predict
+    from object_detection_amd.retinanet import Detections
+    cfg = synthetic.CFG1
+    model = _model(cfg, device)
+    anchors = _anchors(model, cfg, device)
+    sizes = synthetic.level_sizes(cfg)
+    head = synthetic.make_head_outputs(cfg)
+    shapes = [(512, 512)] * cfg.batch
+    split = {k: [t.to(device) for t in v.split(sizes, dim=1)] for k, v in head.items()}
+    model_wh = (512, 512)
+    image_wh = [(1920, 1080), (333, 517)]
+    plain = [{k: v.cpu().clone() for k, v in d.items()} for d in model.postprocess_detections(split, [anchors] * cfg.batch, shapes)]
+    assert all(p["boxes"].shape[0] > 1 for p in plain)
+    expect = [tv.predict_tail({k: v.clone() for k, v in p.items()}, wh, model_wh, 0.3, float_rule=True)
+              for p, wh in zip(plain, image_wh)]
+    assert any(e[0].shape[0] < p["boxes"].shape[0] for e, p in zip(expect, plain))   # the second NMS removes something
+    # (1) the lazy list of one postprocess call
+    dets = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    out = predict.rescale_nms(dets, image_wh, model_wh, 0.3)
+    assert all(isinstance(d, Detections) and d._pending is not None for d in dets)   # still nobody looked
+    for o, d, p, wh, e in zip(out, dets, plain, image_wh, expect):
+        assert o["boxes"].dtype is torch.int32
+        assert torch.equal(o["boxes"].cpu(), e[0]) and torch.equal(o["scores"].cpu(), e[1])
+        assert torch.equal(o["labels"].cpu(), e[2])
+        ratio = torch.tensor([wh[0] / model_wh[0], wh[1] / model_wh[1]] * 2)
+        assert torch.equal(d["boxes"].cpu(), p["boxes"] * ratio)                    # mul_ semantics: rescaled in place
+    # (2) dictionaries somebody already looked at, lists of unequal length
+    mat = [{k: v.to(device) for k, v in p.items()} for p in plain]
+    out2 = predict.rescale_nms(mat, image_wh, model_wh, 0.3)
+    for o, m, p, wh, e in zip(out2, mat, plain, image_wh, expect):
+        assert torch.equal(o["boxes"].cpu(), e[0]) and torch.equal(o["scores"].cpu(), e[1])
+        assert torch.equal(o["labels"].cpu(), e[2])
+        ratio = torch.tensor([wh[0] / model_wh[0], wh[1] / model_wh[1]] * 2)
+        assert torch.equal(m["boxes"].cpu(), p["boxes"] * ratio)

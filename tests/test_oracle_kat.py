@@ -190,3 +190,32 @@ def test_golden_fixtures_match_oracle():
         assert d["boxes"].shape == p[f"boxes{i}"].shape
         assert np.allclose(d["boxes"].numpy(), p[f"boxes{i}"], rtol=1e-5, atol=1e-4)
         assert np.allclose(d["scores"].numpy(), p[f"scores{i}"], rtol=1e-5)
+
+
+def test_predict_tail_restatements_agree():
+    """reference predict.py:66-76 for one image: the torch restatement against the scalar C route (fp32 products in
+    numpy, orc_nms, truncation), both threshold rules, and the hand-derived IoU == float(0.3) case."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, tv_reference as tv
+    gen = torch.Generator().manual_seed(77)
+    xy = torch.rand((300, 2), generator=gen) * 200
+    boxes = torch.cat([xy, xy + torch.rand((300, 2), generator=gen) * 80 + 1], dim=1)
+    scores = torch.rand(300, generator=gen).sort(descending=True)[0]
+    labels = torch.randint(1, 4, (300,), generator=gen)
+    for float_rule in (False, True):
+        pred = {"boxes": boxes.clone(), "scores": scores, "labels": labels}
+        tb, ts, tl, tk = tv.predict_tail(pred, (1920, 1080), (1024, 768), 0.3, float_rule)
+        ratio = np.array([1920 / 1024, 1080 / 768] * 2, dtype=np.float32)
+        scaled = boxes.numpy() * ratio
+        ck = c_oracle.nms(scaled, scores.numpy(), 0.3, float_rule)
+        assert np.array_equal(ck, tk.numpy()) and 0 < len(ck) < 300
+        assert np.array_equal(np.trunc(scaled[ck]).astype(np.int32), tb.numpy())
+        assert np.array_equal(pred["boxes"].numpy(), scaled)
+        assert torch.equal(ts, scores[tk]) and torch.equal(tl, labels[tk])
+    kat = {"boxes": torch.tensor([[0., 0., 20., 20.], [0., 0., 20., 6.], [40., 40., 61., 61.]]),
+           "scores": torch.tensor([0.9, 0.8, 0.7]), "labels": torch.tensor([1, 2, 3])}
+    b, _, l, k = tv.predict_tail({k_: v.clone() for k_, v in kat.items()}, (512, 512), (1024, 1024), 0.3, False)
+    assert k.tolist() == [0, 2] and b.tolist() == [[0, 0, 10, 10], [20, 20, 30, 30]] and l.tolist() == [1, 3]
+    _, _, _, k = tv.predict_tail({k_: v.clone() for k_, v in kat.items()}, (512, 512), (1024, 1024), 0.3, True)
+    assert k.tolist() == [0, 1, 2]
