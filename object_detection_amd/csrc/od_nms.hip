@@ -736,8 +736,10 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     __shared__ float s_area[PT_MAX];
     __shared__ float s_score[PT_MAX];                               // scores as given
     __shared__ int s_src[PT_MAX];                                   // index as given of the r-th best
+    __shared__ long long s_lab[PT_MAX];                             // labels in score order
     __shared__ unsigned long long s_mask[PT_WORDS];
-    __shared__ int s_nk;
+    __shared__ unsigned long long s_keptw[PT_NB];                   // kept rows of every block
+    __shared__ int s_pre[PT_NB + 1];                                // kept rows before every block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x;
@@ -748,11 +750,13 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     // ---- 1. scale, order ------------------------------------------------------------------------------------
     float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
     float sc = 0.0f;
+    long long lab = 0;
     if (tid < n) {
         const float4 r = a.ratio[b];
         const float4 raw = a.boxes[base + tid];
-        bx = make_float4(raw.x * r.x, raw.y * r.y, raw.z * r.z, raw.w * r.w);
         sc = a.scores[base + tid];
+        lab = a.labels[base + tid];
+        bx = make_float4(raw.x * r.x, raw.y * r.y, raw.z * r.z, raw.w * r.w);
         s_score[tid] = sc;
         if (a.scaled_boxes) a.scaled_boxes[base + tid] = bx;
     }
@@ -768,37 +772,64 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         s_box[rank] = bx;
         s_area[rank] = (bx.z - bx.x) * (bx.w - bx.y);
         s_src[rank] = tid;
+        s_lab[rank] = lab;
     }
-    if (tid == 0) s_nk = 0;
     __syncthreads();
 
     // ---- 2. suppression words of the upper triangle ----------------------------------------------------------
+    // unit = 16 rows of a (row block R, column block w) tile, handed out round-robin to the sixteen waves
     ThrBand thr;
     thr.up = a.thr_up;
     thr.lo = a.thr_up * (1.0f - 1e-5f);
     thr.hi = a.thr_up * (1.0f + 1e-5f);
     thr.usable = (a.thr_up > 1e-30f) && (a.thr_up < 1e30f);
     const int nb = (n + 63) >> 6;
-    const int tiles = nb * (nb + 1) / 2;
-    for (int t = wave; t < tiles; t += NT / 64) {
-        int R = 0, rest = t;                       // tile t -> (row block R, column block w), R <= w < nb
+    const int units = 4 * (nb * (nb + 1) / 2);
+    for (int u = wave; u < units; u += NT / 64) {
+        int R = 0, rest = u >> 2;                  // tile -> (row block R, column block w), R <= w < nb
         while (rest >= nb - R) { rest -= nb - R; ++R; }
         const int w = R + rest;
         const int j = 64 * w + lane;
         const bool jv = j < n;
         const float4 cj = s_box[jv ? j : 0];
         const float aj = s_area[jv ? j : 0];
-        const int rows = (n - 64 * R) < 64 ? (n - 64 * R) : 64;
-        unsigned long long* out = s_mask + pt_block_base(R) + rest;
+        const int r0 = 16 * (u & 3);
         const int pitch = PT_NB - R;
-        for (int r = 0; r < rows; ++r) {
-            const int i = 64 * R + r;
-            const float4 bi = s_box[i];
-            const float ai = s_area[i];
-            const float inter = intersection(bi, cj);
-            const bool sup = over_threshold(inter, ai, aj, thr) && jv && j > i;
-            const unsigned long long word = __ballot(sup);
-            if (lane == 0) out[r * pitch] = word;
+        unsigned long long* out = s_mask + pt_block_base(R) + rest + r0 * pitch;
+        const int i0 = 64 * R + r0;
+        if (i0 >= n) continue;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+            float4 bi[4];
+            float ai[4], inter[4], den[4];
+            bool above[4];
+            unsigned long long unsure = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {           // rows past n read row n-1 again; their words are never used
+                const int i = (i0 + q + k) < n ? (i0 + q + k) : (n - 1);
+                bi[k] = s_box[i];
+                ai[k] = s_area[i];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                inter[k] = intersection(bi[k], cj);
+                den[k] = (ai[k] + aj) - inter[k];
+                const float ph = thr.hi * den[k], pl = thr.lo * den[k];
+                above[k] = inter[k] >= ph;
+                const bool below = inter[k] <= pl;
+                const bool safe = (pl > 1e-30f) && (ph < 1e38f);
+                unsure |= __ballot(!(above[k] || below) || !safe);
+            }
+            if (unsure != 0ull || !thr.usable) {    // some pair is too close to the threshold for the products to decide
+#pragma unroll
+                for (int k = 0; k < 4; ++k) above[k] = (inter[k] / den[k]) >= thr.up;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = i0 + q + k;
+                const unsigned long long word = __ballot(above[k] && jv && j > i);
+                if (lane == 0) out[(q + k) * pitch] = word;
+            }
         }
     }
     __syncthreads();
@@ -817,40 +848,52 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
             const int pitch = PT_NB - c;
             const unsigned long long* row = s_mask + pt_block_base(c) + lane * pitch;
             const bool iv = i < n;
-            const unsigned long long diag = iv ? row[0] : 0ull;
-            unsigned long long kept = 0, rem = alive;
+            // the row's words for this and all later blocks are requested together
+            unsigned long long rw[PT_NB];
+#pragma unroll
+            for (int k = 0; k < PT_NB; ++k) rw[k] = (iv && c + k < nb) ? row[k] : 0ull;
+            const unsigned long long diag = rw[0];
+            // only rows that suppress something inside the block need their turn; the others are kept if alive
+            unsigned long long rem = alive & __ballot(diag != 0ull);
             while (rem) {
                 const int r = __builtin_ctzll(rem);
-                kept |= 1ull << r;
                 const uint32_t dlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, r);
                 const uint32_t dhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(diag >> 32), r);
                 alive &= ~(((unsigned long long)dhi << 32) | dlo);
-                rem = alive & ~((2ull << r) - 1ull);
+                rem &= alive & ~((2ull << r) - 1ull);
             }
+            const unsigned long long kept = alive;
             const bool mine = (kept >> lane) & 1ull;
-            for (int w = c + 1; w < nb; ++w) {     // what the newly kept rows suppress in later blocks
-                const unsigned long long v = mine ? row[w - c] : 0ull;
+#pragma unroll
+            for (int k = 1; k < PT_NB; ++k) {      // what the newly kept rows suppress in later blocks
+                if (c + k >= nb) break;
+                const unsigned long long v = mine ? rw[k] : 0ull;
                 if (__ballot(v != 0ull) == 0ull) continue;
                 const unsigned long long all = ((unsigned long long)wave_or_all((uint32_t)(v >> 32)) << 32) |
                                                wave_or_all((uint32_t)v);
-                if (lane == w) pending |= all;
+                if (lane == c + k) pending |= all;
             }
-            if (mine) {
-                const int pos = nk + mbcnt(kept);
-                const int src = s_src[i];
-                const float4 k = s_box[i];
-                a.out_boxes[base + pos] = make_int4((int)k.x, (int)k.y, (int)k.z, (int)k.w);
-                a.out_scores[base + pos] = s_score[src];
-                a.out_labels[base + pos] = a.labels[base + src];
-                if (a.keep_idx) a.keep_idx[base + pos] = src;
-            }
+            if (lane == 0) { s_keptw[c] = kept; s_pre[c] = nk; }
             nk += __popcll(kept);
         }
-        if (lane == 0) { s_nk = nk; a.out_count[b] = nk; }
+        if (lane == 0) { s_pre[nb] = nk; a.out_count[b] = nk; }
     }
     __syncthreads();
-    // ---- 4. rows past the count are zero ----------------------------------------------------------------------
-    for (int k = s_nk + tid; k < a.max_det; k += NT) {
+    // ---- 4. outputs: kept rows in order, zeros past the count --------------------------------------------------
+    const int nk = s_pre[nb];
+    if (tid < n) {
+        const unsigned long long kw = s_keptw[wave];
+        if ((kw >> lane) & 1ull) {
+            const int pos = s_pre[wave] + mbcnt(kw);
+            const int src = s_src[tid];
+            const float4 k = s_box[tid];
+            a.out_boxes[base + pos] = make_int4((int)k.x, (int)k.y, (int)k.z, (int)k.w);
+            a.out_scores[base + pos] = s_score[src];
+            a.out_labels[base + pos] = s_lab[tid];
+            if (a.keep_idx) a.keep_idx[base + pos] = src;
+        }
+    }
+    for (int k = nk + tid; k < a.max_det; k += NT) {
         a.out_boxes[base + k] = make_int4(0, 0, 0, 0);
         a.out_scores[base + k] = 0.0f;
         a.out_labels[base + k] = 0;
