@@ -38,6 +38,10 @@ namespace {
 using namespace od;
 
 constexpr int MT = 256;          // threads per workgroup = 4 independent waves
+#ifndef OD_ASSIGN_LDS
+#define OD_ASSIGN_LDS 0          // experiment knob (tools/exp_build.sh): unused LDS per workgroup caps the kernel's
+#endif                           // waves per CU, which leaves room for another stream's kernel beside it
+constexpr int ASSIGN_LDS = OD_ASSIGN_LDS;
 #ifndef OD_R
 #define OD_R 4
 #endif
@@ -1053,7 +1057,7 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                          0, s, ws, (long long)m_total, (int)batch, restore);
     }
     const long long stride = (long long)anchor_batch_stride;
-    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), 0, s, (const float4*)anchors, stride,
+    OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), ASSIGN_LDS, s, (const float4*)anchors, stride,
                      (long long)n, wtiles, layout, image_fastest, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
                      (long long*)matched);
     if (m_total > HEAVY) {
