@@ -133,11 +133,13 @@ __device__ __forceinline__ int wave_inclusive_sum(int v) {
 // the exact threshold leaves a zero key in its slot (rare: the prefilter bound is within 0.1 % of the
 // threshold); the select kernel ignores zero keys.  The kernel is a stream: everything a wave does after its
 // loads is kept free of further memory round trips, which under load cost as much as the loads themselves.
-__global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
-                                                    unsigned int* __restrict__ key_count,
-                                                    unsigned int* __restrict__ key_valid,
-                                                    unsigned int* __restrict__ key_count_redo,
-                                                    const CutInfo* __restrict__ cuts, int redo, int chunk_base) {
+// One 8192-logit chunk of image b, by one workgroup of ST threads (all of them call it with the same arguments).
+__device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned long long* __restrict__ keys,
+                                             unsigned int* __restrict__ key_count,
+                                             unsigned int* __restrict__ key_valid,
+                                             unsigned int* __restrict__ key_count_redo,
+                                             const CutInfo* __restrict__ cuts, const int redo, const int chunk,
+                                             const int b) {
     constexpr int ITERS = CHUNK / (ST * 4);
     constexpr int QCAP = 512;                      // queue entries per wave and pass
     static_assert(ITERS == 8, "eight 16-byte loads per thread; the select tree picks one of 32 values");
@@ -147,8 +149,6 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
     __shared__ unsigned int s_valid;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int chunk = (int)blockIdx.x + chunk_base;   // chunk_base: the chunks of leading deferred levels are not launched
-    const int b = blockIdx.y;
     int l = 0;
 #pragma unroll
     for (int i = 1; i < OD_MAX_LEVELS; ++i)
@@ -296,6 +296,49 @@ __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned lon
             if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
         }
         for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
+    }
+}
+
+__global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
+                                                    unsigned int* __restrict__ key_count,
+                                                    unsigned int* __restrict__ key_valid,
+                                                    unsigned int* __restrict__ key_count_redo,
+                                                    const CutInfo* __restrict__ cuts, int chunk_base) {
+    // chunk_base: the chunks of leading deferred levels are not launched
+    filter_chunk(p, keys, key_count, key_valid, key_count_redo, cuts, 0, (int)blockIdx.x + chunk_base, (int)blockIdx.y);
+}
+
+// Second pass over the levels whose sampled cut left fewer than K valid keys, without the cut.  That almost never
+// happens, so the launch is a narrow one -- REDO_WG workgroups per image, which look at the image's levels and leave at
+// once when none needs the pass (a launch of one workgroup per chunk cost the chip 4-6 us per call to find that out);
+// when a level does need it, the image's workgroups walk that level's chunks in turn.
+constexpr int REDO_WG = 24;
+__global__ __launch_bounds__(ST) void filter_redo_kernel(FilterParams p, unsigned long long* __restrict__ keys,
+                                                         unsigned int* __restrict__ key_count,
+                                                         unsigned int* __restrict__ key_valid,
+                                                         unsigned int* __restrict__ key_count_redo,
+                                                         const CutInfo* __restrict__ cuts, int total_chunks) {
+    const int b = blockIdx.y;
+    bool need[OD_MAX_LEVELS];
+    bool any = false;
+#pragma unroll
+    for (int l = 0; l < OD_MAX_LEVELS; ++l) {
+        need[l] = false;
+        if (l < p.num_levels && !p.defer[l]) {
+            const long long slot = (long long)b * p.num_levels + l;
+            need[l] = cuts[slot].active && key_valid[slot * CSTRIDE] < (unsigned int)p.topk;
+        }
+        any = any || need[l];
+    }
+    if (!any) return;
+#pragma unroll
+    for (int l = 0; l < OD_MAX_LEVELS; ++l) {
+        if (!need[l]) continue;
+        const int end = (l + 1 < p.num_levels) ? p.chunk_start[l + 1] : total_chunks;
+        for (int chunk = p.chunk_start[l] + (int)blockIdx.x; chunk < end; chunk += REDO_WG) {
+            filter_chunk(p, keys, key_count, key_valid, key_count_redo, cuts, 1, chunk, b);
+            __syncthreads();                       // the queues and counters in LDS are reused by the next chunk
+        }
     }
 }
 
@@ -1273,7 +1316,7 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
         const dim3 grid((unsigned)(lay.total_chunks - chunk_base), (unsigned)batch);
         if (grid.x > 0)
             OD_LAUNCH_KERNEL(OD_KERNEL_FILTER, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count, key_valid,
-                             key_count_redo, (const CutInfo*)cuts, 0, chunk_base);
+                             key_count_redo, (const CutInfo*)cuts, chunk_base);
         for (int l = 0; l < num_levels; ++l) {
             if (!fp.defer[l]) continue;
             const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
@@ -1282,8 +1325,9 @@ int select_candidates_impl(const float* const* cls_logits, const int64_t* cls_ba
         }
         if (sampled) {
             if (grid.x > 0)
-                OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_kernel, grid, dim3(ST), 0, s, fp, keys, key_count,
-                                 key_valid, key_count_redo, (const CutInfo*)cuts, 1, chunk_base);
+                OD_LAUNCH_KERNEL(OD_KERNEL_FILTER_REDO, filter_redo_kernel, dim3((unsigned)REDO_WG, (unsigned)batch),
+                                 dim3(ST), 0, s, fp, keys, key_count, key_valid, key_count_redo, (const CutInfo*)cuts,
+                                 (int)lay.total_chunks);
             for (int l = 0; l < num_levels; ++l) {
                 if (!fp.defer[l]) continue;
                 const long long units = ((fp.level_elems[l] + CHUNK - 1) / CHUNK + SUBS - 1) / SUBS;
