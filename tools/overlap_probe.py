@@ -116,3 +116,11 @@ for k, name in enumerate(_C.KERNEL_NAMES):
     ms, n = _C.profile_read(k)
     _C.profile_select(_C.PROFILE_OFF)
     print(f"  {name:14s} {1e3 * ms / max(n, 1):7.1f}   ({n} launches timed, step {ms_step:.4f} ms)")
+
+# the matching chain without its last kernel (no low-quality restore): does a shorter chain shorten the step?
+_C.profile_stride(1)
+model.proposal_matcher.allow_low_quality_matches = False
+for n_post, n_match in ((0, 1), (0, 2), (2, 1), (3, 1)):
+    ms, host = run(n_post, n_match)
+    print(f"[no restore kernel] inference streams {n_post}, matching streams {n_match}: {ms:.4f} ms per step")
+model.proposal_matcher.allow_low_quality_matches = True
