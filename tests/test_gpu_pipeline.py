@@ -788,3 +788,17 @@ def test_prediction_loop_tail_on_model_detections(device):
         assert torch.equal(o["labels"].cpu(), e[2])
         ratio = torch.tensor([wh[0] / model_wh[0], wh[1] / model_wh[1]] * 2)
         assert torch.equal(m["boxes"].cpu(), p["boxes"] * ratio)
+
+
+@pytest.mark.parametrize("section,cases", [("match", 60), ("select", 60), ("nms", 150), ("nms_segments", 150),
+                                           ("fcos", 100), ("tail", 300)])
+def test_random_shapes_against_the_scalar_checker(device, section, cases):
+    """A fixed run of the randomised parity tool (tools/fuzz_parity.py): ragged pyramids and GT lists, level sizes from
+    1 to 300 000 logits with 1 ... 91 classes, NMS in both branches under both threshold rules, the prediction tail --
+    every case bit for bit against oracle/od_oracle.c."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    bad = fuzz.run_seeds(section, range(1000, 1000 + cases))
+    assert not bad, bad[:3]
