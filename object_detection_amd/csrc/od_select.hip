@@ -20,6 +20,7 @@
 // left.  Those are bitonic-sorted (registers + lane shuffles + LDS), and the first K are decoded and
 // clipped straight into the padded candidate arrays.
 #include "od_common.h"
+#include <type_traits>
 #include "../../include/od_boxes.h"
 
 namespace {
@@ -199,26 +200,43 @@ __device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned lon
         };
         v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
     }
-    unsigned int pending_all = 0u;                 // bit it*4+k: that element may reach the threshold
-    auto mark = [&](const vec4f& v, int it) {
-        unsigned int m = 0u;
-        m |= !(v.x <= pre) ? 1u : 0u; m |= !(v.y <= pre) ? 2u : 0u;
-        m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
-        pending_all |= m << (it * 4);
+    // Which elements may reach the threshold is decided per element for the whole wave: one compare gives the lane mask
+    // of element e (a ballot, in scalar registers), its population count is scalar arithmetic, and an element that no
+    // lane passes -- nearly all of them under a sampled cut -- costs nothing more; the lanes that pass write (logit,
+    // position) straight to the wave's queue.  (Collecting a bit mask per lane first and then picking each lane's
+    // elements out of its 32 registers with a select tree cost 250-370 vector instructions per wave.)
+    const bool every = !prefilter;                  // threshold <= 0: every element inside the chunk is scored
+    const bool partial = len < CHUNK;               // the level's last chunk: elements past its end are never candidates
+    unsigned long long* queue = s_queue[wave];
+    int pos = 0;                                    // wave-uniform: candidates met so far
+    // FAST: the usual chunk (a bound on the logit exists, the chunk is whole) tests one compare per element
+    auto emit_all = [&](auto fast) {
+        constexpr bool FAST = decltype(fast)::value;
+        auto emit1 = [&](float x, int e) {
+            bool c;
+            if constexpr (FAST) {
+                c = !(x <= pre);
+            } else {
+                c = every || !(x <= pre);
+                if (partial) c = c && ((e >> 2) * (ST * 4) + tid * 4 + (e & 3) < len);
+            }
+            const unsigned long long m = __ballot(c);
+            if (m != 0ull) {
+                const int n = __popcll(m);
+                if (c && pos + n <= QCAP) {         // a queue that overflows is refilled group by group below
+                    const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+                    queue[pos + mbcnt(m)] = ((unsigned long long)f2u(x) << 32) | off;     // (logit, position in the chunk)
+                }
+                pos += n;
+            }
+        };
+        auto emit4 = [&](const vec4f& v, int it) {
+            emit1(v.x, it * 4 + 0); emit1(v.y, it * 4 + 1); emit1(v.z, it * 4 + 2); emit1(v.w, it * 4 + 3);
+        };
+        emit4(v0, 0); emit4(v1, 1); emit4(v2, 2); emit4(v3, 3); emit4(v4, 4); emit4(v5, 5); emit4(v6, 6); emit4(v7, 7);
     };
-    if (prefilter) {
-        mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
-    } else {
-        pending_all = 0xffffffffu;                 // threshold <= 0: every element is scored
-    }
-    if (len < CHUNK) {
-        unsigned int in_range = 0u;
-#pragma unroll
-        for (int i = 0; i < ITERS * 4; ++i)
-            in_range |= ((i >> 2) * ST * 4 + tid * 4 + (i & 3) < len) ? (1u << i) : 0u;
-        pending_all &= in_range;
-    }
-    const int all_total = (int)wave_sum_all((uint32_t)__popc(pending_all));
+    if (!every && !partial) emit_all(std::true_type{}); else emit_all(std::false_type{});
+    const int all_total = pos;
     if (lane == 0) s_tot[wave] = all_total;
     __syncthreads();
     int wg_total = 0, before_me = 0;
@@ -234,46 +252,13 @@ __device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned lon
 
     unsigned long long* dst = keys + (long long)b * p.keys_per_image + p.key_off[l];
     unsigned int* counter = (redo ? key_count_redo : key_count) + slot * CSTRIDE;
-    unsigned long long* queue = s_queue[wave];
-    // Usual case: every wave's queue holds all its candidates; the workgroup reserves its slots with ONE
-    // atomic, requested before the scoring.  Otherwise each wave makes four passes of 8 element slots
-    // (at most 64 * 8 = QCAP entries each) with a reservation of its own per pass.
-    unsigned int wg_base = 0;                      // requested now, stored to LDS only after the scoring
-    if (one_pass && tid == 0) wg_base = atomicAdd(counter, (unsigned int)wg_total);
-    const int passes = one_pass ? 1 : 4;
-    for (int ps = 0; ps < passes; ++ps) {
-        unsigned int pending = one_pass ? pending_all : (pending_all & (0xffu << (8 * ps)));
-        const int mine = __popc(pending);
-        const int incl = wave_inclusive_sum(mine);
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        unsigned int base = 0;
-        if (!one_pass && total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
-        int pos = incl - mine;
-        while (pending) {
-            const int e = __ffs(pending) - 1;
-            pending &= pending - 1u;
-            // xe = element e through a select tree
-            const bool b0 = e & 1, b1 = e & 2;
-            const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
-            const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
-            const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
-            const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
-            const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
-            const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
-            const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
-            const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
-            const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
-            const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
-            const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
-            const float xe = b4 ? h1 : h0;
-            const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
-            queue[pos++] = ((unsigned long long)f2u(xe) << 32) | off;     // (logit, position in the chunk)
-        }
+    // every lane scores its own queue entry and overwrites it with the key; returns the valid keys of the wave
+    auto score_queue = [&](int total) -> int {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the queue is read by other lanes of this wave
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int nvalid = 0;                            // valid keys of this wave and pass
-        for (int i0 = 0; i0 < total; i0 += 64) {   // every lane scores its own entry and overwrites it with the key
+        int nvalid = 0;
+        for (int i0 = 0; i0 < total; i0 += 64) {
             bool ok = false;
             if (i0 + lane < total) {
                 const unsigned long long ent = queue[i0 + lane];
@@ -284,18 +269,56 @@ __device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned lon
             }
             nvalid += __popcll(__ballot(ok));
         }
+        return nvalid;
+    };
+    if (one_pass) {
+        // Usual case: every wave's queue holds all its candidates; the workgroup reserves its slots with ONE atomic,
+        // requested before the scoring, so that its round trip overlaps it.
+        unsigned int wg_base = 0;
+        if (tid == 0) wg_base = atomicAdd(counter, (unsigned int)wg_total);
+        const int nvalid = score_queue(all_total);
         // valid keys per (image, level): decides after the kernel whether the sampled cut was low enough
-        if (one_pass) {
-            if (lane == 0 && nvalid) atomicAdd(&s_valid, (unsigned int)nvalid);
-            if (tid == 0) s_base = wg_base;
-            __syncthreads();
-            base = s_base + (unsigned int)before_me;
-            if (tid == 0 && !redo && s_valid) atomicAdd(key_valid + slot * CSTRIDE, s_valid);
-        } else {
-            base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
-            if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
-        }
-        for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
+        if (lane == 0 && nvalid) atomicAdd(&s_valid, (unsigned int)nvalid);
+        if (tid == 0) s_base = wg_base;
+        __syncthreads();
+        const unsigned int base = s_base + (unsigned int)before_me;
+        if (tid == 0 && !redo && s_valid) atomicAdd(key_valid + slot * CSTRIDE, s_valid);
+        for (int i = lane; i < all_total; i += 64) dst[base + i] = queue[i];   // own entries: no cross-lane hazard
+        return;
+    }
+    // Dense chunk (no cut, low threshold): some wave has more candidates than its queue holds.  Every wave then makes
+    // four passes of eight elements (at most 64 * 8 = QCAP entries each) with a slot reservation of its own per pass.
+#pragma nounroll
+    for (int ps = 0; ps < 4; ++ps) {
+        __builtin_amdgcn_wave_barrier();           // the previous pass has copied its keys out of the queue
+        pos = 0;
+        // the pass's two registers, made opaque so that the element tests of all passes are not hoisted out of the loop
+        vec4f a = ps == 0 ? v0 : (ps == 1 ? v2 : (ps == 2 ? v4 : v6));
+        vec4f c = ps == 0 ? v1 : (ps == 1 ? v3 : (ps == 2 ? v5 : v7));
+        asm volatile("" : "+v"(a), "+v"(c));
+        auto emit4_at = [&](const vec4f& v, int it_in_pass) {
+            // element index e = (2 * ps + it_in_pass) * 4 + k: the position arithmetic below takes it at run time
+            const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int it = 2 * ps + it_in_pass;
+                const unsigned int off = (unsigned int)(it * (ST * 4) + tid * 4 + k);
+                bool cnd = every || !(xs[k] <= pre);
+                if (partial) cnd = cnd && ((int)off < len);
+                const unsigned long long m = __ballot(cnd);
+                if (cnd) queue[pos + mbcnt(m)] = ((unsigned long long)f2u(xs[k]) << 32) | off;
+                pos += __popcll(m);
+            }
+        };
+        emit4_at(a, 0);
+        emit4_at(c, 1);
+        const int total = pos;
+        unsigned int base = 0;
+        if (total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
+        const int nvalid = score_queue(total);
+        base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
+        if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
+        for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];
     }
 }
 
