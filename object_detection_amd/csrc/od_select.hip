@@ -288,30 +288,21 @@ __device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned lon
     }
     // Dense chunk (no cut, low threshold): some wave has more candidates than its queue holds.  Every wave then makes
     // four passes of eight elements (at most 64 * 8 = QCAP entries each) with a slot reservation of its own per pass.
-#pragma nounroll
-    for (int ps = 0; ps < 4; ++ps) {
+    // (the two registers of a pass are named at the call: picking them by a run-time pass number would move all
+    // eight to scratch memory)
+    auto dense_pass = [&](const vec4f& ga, const vec4f& gc, int it0) {
         __builtin_amdgcn_wave_barrier();           // the previous pass has copied its keys out of the queue
         pos = 0;
-        // the pass's two registers, made opaque so that the element tests of all passes are not hoisted out of the loop
-        vec4f a = ps == 0 ? v0 : (ps == 1 ? v2 : (ps == 2 ? v4 : v6));
-        vec4f c = ps == 0 ? v1 : (ps == 1 ? v3 : (ps == 2 ? v5 : v7));
-        asm volatile("" : "+v"(a), "+v"(c));
-        auto emit4_at = [&](const vec4f& v, int it_in_pass) {
-            // element index e = (2 * ps + it_in_pass) * 4 + k: the position arithmetic below takes it at run time
-            const float xs[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int it = 2 * ps + it_in_pass;
-                const unsigned int off = (unsigned int)(it * (ST * 4) + tid * 4 + k);
-                bool cnd = every || !(xs[k] <= pre);
-                if (partial) cnd = cnd && ((int)off < len);
-                const unsigned long long m = __ballot(cnd);
-                if (cnd) queue[pos + mbcnt(m)] = ((unsigned long long)f2u(xs[k]) << 32) | off;
-                pos += __popcll(m);
-            }
+        auto e1 = [&](float x, int e) {
+            const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+            bool cnd = every || !(x <= pre);
+            if (partial) cnd = cnd && ((int)off < len);
+            const unsigned long long m = __ballot(cnd);
+            if (cnd) queue[pos + mbcnt(m)] = ((unsigned long long)f2u(x) << 32) | off;
+            pos += __popcll(m);
         };
-        emit4_at(a, 0);
-        emit4_at(c, 1);
+        e1(ga.x, it0 * 4 + 0); e1(ga.y, it0 * 4 + 1); e1(ga.z, it0 * 4 + 2); e1(ga.w, it0 * 4 + 3);
+        e1(gc.x, it0 * 4 + 4); e1(gc.y, it0 * 4 + 5); e1(gc.z, it0 * 4 + 6); e1(gc.w, it0 * 4 + 7);
         const int total = pos;
         unsigned int base = 0;
         if (total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
@@ -319,7 +310,8 @@ __device__ __forceinline__ void filter_chunk(const FilterParams& p, unsigned lon
         base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
         if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
         for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];
-    }
+    };
+    dense_pass(v0, v1, 0); dense_pass(v2, v3, 2); dense_pass(v4, v5, 4); dense_pass(v6, v7, 6);
 }
 
 __global__ __launch_bounds__(ST) void filter_kernel(FilterParams p, unsigned long long* __restrict__ keys,
@@ -375,7 +367,7 @@ __global__ __launch_bounds__(ST) void filter_redo_kernel(FilterParams p, unsigne
 constexpr long long DEFER_MIN = 8ll << 20;
 constexpr int SUBS = 8;
 
-__global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l, unsigned long long* __restrict__ keys,
+__global__ __launch_bounds__(ST) __attribute__((amdgpu_waves_per_eu(4))) void filter_defer_kernel(FilterParams p, int l, unsigned long long* __restrict__ keys,
                                                           unsigned int* __restrict__ key_count,
                                                           unsigned int* __restrict__ key_valid,
                                                           unsigned int* __restrict__ key_count_redo,
@@ -465,26 +457,30 @@ __global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l,
             };
             v0 = ld4(0); v1 = ld4(1); v2 = ld4(2); v3 = ld4(3); v4 = ld4(4); v5 = ld4(5); v6 = ld4(6); v7 = ld4(7);
         }
-        unsigned int pending_all = 0u;             // bit it*4+k: that element may reach the threshold
-        auto mark = [&](const vec4f& v, int it) {
-            unsigned int m = 0u;
-            m |= !(v.x <= pre) ? 1u : 0u; m |= !(v.y <= pre) ? 2u : 0u;
-            m |= !(v.z <= pre) ? 4u : 0u; m |= !(v.w <= pre) ? 8u : 0u;
-            pending_all |= m << (it * 4);
+        // candidates per element of the whole wave: one compare and a ballot each (see filter_chunk); counted first,
+        // because the workgroup has to know whether the queues can take them, then written behind what the queue holds
+        const bool every = !prefilter;
+        const bool partial = len < CHUNK;
+        auto passes_bound = [&](auto fast, float x, int e) -> bool {
+            if constexpr (decltype(fast)::value) {
+                return !(x <= pre);
+            } else {
+                bool c = every || !(x <= pre);
+                if (partial) c = c && ((e >> 2) * (ST * 4) + tid * 4 + (e & 3) < len);
+                return c;
+            }
         };
-        if (prefilter) {
-            mark(v0, 0); mark(v1, 1); mark(v2, 2); mark(v3, 3); mark(v4, 4); mark(v5, 5); mark(v6, 6); mark(v7, 7);
-        } else {
-            pending_all = 0xffffffffu;
-        }
-        if (len < CHUNK) {
-            unsigned int in_range = 0u;
-#pragma unroll
-            for (int i = 0; i < 32; ++i)
-                in_range |= ((i >> 2) * ST * 4 + tid * 4 + (i & 3) < len) ? (1u << i) : 0u;
-            pending_all &= in_range;
-        }
-        const int my_total = (int)wave_sum_all((uint32_t)__popc(pending_all));
+        auto count_all = [&](auto fast) -> int {
+            int t = 0;
+            auto c4 = [&](const vec4f& v, int it) {
+                t += __popcll(__ballot(passes_bound(fast, v.x, it * 4 + 0))) + __popcll(__ballot(passes_bound(fast, v.y, it * 4 + 1))) +
+                     __popcll(__ballot(passes_bound(fast, v.z, it * 4 + 2))) + __popcll(__ballot(passes_bound(fast, v.w, it * 4 + 3)));
+            };
+            c4(v0, 0); c4(v1, 1); c4(v2, 2); c4(v3, 3); c4(v4, 4); c4(v5, 5); c4(v6, 6); c4(v7, 7);
+            return t;
+        };
+        const bool usual = !every && !partial;
+        const int my_total = usual ? count_all(std::true_type{}) : count_all(std::false_type{});
         if (lane == 0) s_tot[sub & 1][wave] = my_total;
         __syncthreads();                           // (two buffers: the next chunk writes the other one)
         int tot[NWV];
@@ -496,27 +492,39 @@ __global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l,
             dense = dense || (tot[w] > QCAP);
         }
         if (!fits) flush();                        // uniform: every wave sees the same numbers
-        // element e of this thread's 32 through a select tree; appends (logit, position in the chunk) entries
-        auto fill = [&](unsigned int pending, int pos) {
-            while (pending) {
-                const int e = __ffs(pending) - 1;
-                pending &= pending - 1u;
-                const bool b0 = e & 1, b1 = e & 2;
-                const float q0 = b1 ? (b0 ? v0.w : v0.z) : (b0 ? v0.y : v0.x);
-                const float q1 = b1 ? (b0 ? v1.w : v1.z) : (b0 ? v1.y : v1.x);
-                const float q2 = b1 ? (b0 ? v2.w : v2.z) : (b0 ? v2.y : v2.x);
-                const float q3 = b1 ? (b0 ? v3.w : v3.z) : (b0 ? v3.y : v3.x);
-                const float q4 = b1 ? (b0 ? v4.w : v4.z) : (b0 ? v4.y : v4.x);
-                const float q5 = b1 ? (b0 ? v5.w : v5.z) : (b0 ? v5.y : v5.x);
-                const float q6 = b1 ? (b0 ? v6.w : v6.z) : (b0 ? v6.y : v6.x);
-                const float q7 = b1 ? (b0 ? v7.w : v7.z) : (b0 ? v7.y : v7.x);
-                const bool b2 = e & 4, b3 = e & 8, b4 = e & 16;
-                const float h0 = b3 ? (b2 ? q3 : q2) : (b2 ? q1 : q0);
-                const float h1 = b3 ? (b2 ? q7 : q6) : (b2 ? q5 : q4);
-                const float xe = b4 ? h1 : h0;
+        // appends the (logit, position in the chunk) entries of all 32 elements from queue position `from` on
+        auto fill_all = [&](auto fast, int from) {
+            int pos = from;
+            auto e1 = [&](float x, int e) {
+                const bool c = passes_bound(fast, x, e);
+                const unsigned long long m = __ballot(c);
+                if (m != 0ull) {
+                    const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
+                    if (c) queue[pos + mbcnt(m)] = ((unsigned long long)f2u(x) << 32) | off;
+                    pos += __popcll(m);
+                }
+            };
+            auto e4 = [&](const vec4f& v, int it) {
+                e1(v.x, it * 4 + 0); e1(v.y, it * 4 + 1); e1(v.z, it * 4 + 2); e1(v.w, it * 4 + 3);
+            };
+            e4(v0, 0); e4(v1, 1); e4(v2, 2); e4(v3, 3); e4(v4, 4); e4(v5, 5); e4(v6, 6); e4(v7, 7);
+        };
+        // the same for the eight elements of two registers (one pass over a dense chunk), from position 0; returns
+        // their number.  The registers are named at the call: picking them by a run-time pass number would move all
+        // eight to scratch memory.
+        auto fill_group = [&](const vec4f& ga, const vec4f& gc, int it0) -> int {
+            int pos = 0;
+            auto e1 = [&](float x, int e) {
                 const unsigned int off = (unsigned int)((e >> 2) * (ST * 4) + tid * 4 + (e & 3));
-                queue[pos++] = ((unsigned long long)f2u(xe) << 32) | off;
-            }
+                bool c = every || !(x <= pre);
+                if (partial) c = c && ((int)off < len);
+                const unsigned long long m = __ballot(c);
+                if (c) queue[pos + mbcnt(m)] = ((unsigned long long)f2u(x) << 32) | off;
+                pos += __popcll(m);
+            };
+            e1(ga.x, it0 * 4 + 0); e1(ga.y, it0 * 4 + 1); e1(ga.z, it0 * 4 + 2); e1(ga.w, it0 * 4 + 3);
+            e1(gc.x, it0 * 4 + 4); e1(gc.y, it0 * 4 + 5); e1(gc.z, it0 * 4 + 6); e1(gc.w, it0 * 4 + 7);
+            return pos;
         };
         // scores the queue entries [from, from + n) in place: key, or 0 for a logit that fails the exact test
         auto score = [&](int from, int n) {
@@ -541,9 +549,7 @@ __global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l,
             int mine = 0, had = 0;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) if (w == wave) { mine = tot[w]; had = held[w]; }
-            const int my_cnt = __popc(pending_all);
-            const int incl = wave_inclusive_sum(my_cnt);
-            fill(pending_all, had + incl - my_cnt);
+            if (usual) fill_all(std::true_type{}, had); else fill_all(std::false_type{}, had);
             nvalid_acc += score(had, mine);
 #pragma unroll
             for (int w = 0; w < NWV; ++w) held[w] += tot[w];
@@ -551,19 +557,17 @@ __global__ __launch_bounds__(ST) void filter_defer_kernel(FilterParams p, int l,
             // a chunk some wave cannot hold: nothing is deferred (the queues are empty here, see below); every wave
             // makes four passes of 8 element slots (at most 64 * 8 = QCAP entries) with a reservation of its own
             flush();                               // uniform; empties the queues if `fits` held above
-            for (int ps = 0; ps < 4; ++ps) {
-                const unsigned int pending = pending_all & (0xffu << (8 * ps));
-                const int my_cnt = __popc(pending);
-                const int incl = wave_inclusive_sum(my_cnt);
-                const int total = __builtin_amdgcn_readlane(incl, 63);
+            auto dense_pass = [&](const vec4f& ga, const vec4f& gc, int it0) {
+                __builtin_amdgcn_wave_barrier();   // the previous pass has copied its keys out of the queue
+                const int total = fill_group(ga, gc, it0);
                 unsigned int base = 0;
                 if (total > 0 && lane == 0) base = atomicAdd(counter, (unsigned int)total);
-                fill(pending, incl - my_cnt);
                 const int nvalid = score(0, total);
                 base = (unsigned int)__builtin_amdgcn_readlane((int)base, 0);
                 if (lane == 0 && !redo && nvalid) atomicAdd(key_valid + slot * CSTRIDE, (unsigned int)nvalid);
                 for (int i = lane; i < total; i += 64) dst[base + i] = queue[i];
-            }
+            };
+            dense_pass(v0, v1, 0); dense_pass(v2, v3, 2); dense_pass(v4, v5, 4); dense_pass(v6, v7, 6);
         }
     }
     flush();
