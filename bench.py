@@ -503,9 +503,11 @@ def main():
         # the tensors of every image eight steps after the call (by then the counts have arrived: no wait);
         # `api_deferred`: nobody looks inside the loop; `blocking`: the host looks right after every call.
         n_api = min(args.steps, 100)
-        look = lambda res: [(d["boxes"], d["scores"], d["labels"]) for d in res[1]]
-        ms_api = timed_loop(lambda i: eager_step(i, mode="api"), n_api, consume=look)
-        ms_api_deferred = timed_loop(lambda i: eager_step(i, mode="api"), n_api, consume=lambda res: None, lag=32)
+        # (only the detections are held back for the consumer: keeping the 100 MB matched-index tensor of every step
+        # alive as well would make the matching half write to fresh memory each step, which is not what is measured)
+        look = lambda res: [(d["boxes"], d["scores"], d["labels"]) for d in res]
+        ms_api = timed_loop(lambda i: eager_step(i, mode="api")[1], n_api, consume=look)
+        ms_api_deferred = timed_loop(lambda i: eager_step(i, mode="api")[1], n_api, consume=lambda res: None, lag=32)
         ms_api_blocking = timed_loop(lambda i: eager_step(i, mode="api-blocking"), 20)
         # the two halves on their own (they never run in the same forward of the reference)
         torch.cuda.set_stream(default_stream)
