@@ -242,12 +242,15 @@ int od_pack_detections(const float* boxes, const float* scores, const int64_t* l
  *     outside the int32 range saturate, NaN becomes 0), out_scores fp32, out_labels int64, keep_idx int64 or NULL
  *     (positions inside the image's detection list, as nms returns them), out_count int32 [batch].
  *   Rows past out_count are zero-filled.  Limit: max_det <= 1024 (OD_ERR_LIMIT beyond).
+ *   workspace: od_predict_tail_workspace_bytes(batch, max_det), 256-byte aligned.  Above 128 detections per image the
+ *   suppression matrix of an image is computed by several workgroups, which leave it there for the last one to finish.
  */
 #define OD_MAX_PREDICT_TAIL 1024
+size_t od_predict_tail_workspace_bytes(int32_t batch, int32_t max_det);
 int od_predict_tail(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
                     const float* ratio, int32_t batch, int32_t max_det, double iou_threshold, int32_t mode,
                     float* scaled_boxes, int32_t* out_boxes, float* out_scores, int64_t* out_labels,
-                    int64_t* keep_idx, int32_t* out_count, void* stream);
+                    int64_t* keep_idx, int32_t* out_count, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Classification loss of the RetinaNet head, fused with its target construction.  Replaces torchvision

@@ -56,7 +56,9 @@ SIGNATURES = {
     "od_batched_nms_noalloc": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                          _P, _P, _P, _P, _P, _P]),
     "od_pack_detections": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, _P, _P]),
-    "od_predict_tail": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "od_predict_tail_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "od_predict_tail": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, c_double, c_int32, _P, _P, _P, _P, _P, _P, _P,
+                                  c_size_t, _P]),
     "od_focal_loss_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "od_focal_loss_forward": (c_int32, [_P, c_int32, c_int64, c_int64, c_int32, _P, _P, _P, c_int32, c_float, c_float,
                                         c_int32, _P, _P, _P, _P, c_size_t, _P]),

@@ -729,6 +729,8 @@ struct PredictTailArgs {
     long long* out_labels;
     long long* keep_idx;        // may be null
     int* out_count;
+    unsigned long long* g_mask; // [batch, PT_WORDS]: suppression words of an image whose workgroups share the work
+    int* done;                  // [batch]: workgroups of the image that have written their words (zero at the launch)
 };
 
 __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
@@ -741,8 +743,18 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     __shared__ unsigned long long s_keptw[PT_NB];                   // kept rows of every block
     __shared__ int s_pre[PT_NB + 1];                                // kept rows before every block
 
+    __shared__ int s_last;
+#ifdef PT_STAMPS
+    unsigned long long pst[8];
+#define PSTAMP(k) pst[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+    PSTAMP(0);
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
+    const int G = gridDim.x;                    // workgroups that share the image's suppression matrix
     const long long base = (long long)b * a.max_det;
     int n = a.counts[b];
     n = n < 0 ? 0 : (n > a.max_det ? a.max_det : n);
@@ -758,7 +770,6 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         lab = a.labels[base + tid];
         bx = make_float4(raw.x * r.x, raw.y * r.y, raw.z * r.z, raw.w * r.w);
         s_score[tid] = sc;
-        if (a.scaled_boxes) a.scaled_boxes[base + tid] = bx;
     }
     __syncthreads();
     const bool in_place = !(tid > 0 && tid < n) || s_score[tid - 1] >= sc;
@@ -776,6 +787,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     }
     __syncthreads();
 
+    PSTAMP(1);
     // ---- 2. suppression words of the upper triangle ----------------------------------------------------------
     // unit = 16 rows of a (row block R, column block w) tile, handed out round-robin to the sixteen waves
     ThrBand thr;
@@ -785,7 +797,15 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     thr.usable = (a.thr_up > 1e-30f) && (a.thr_up < 1e30f);
     const int nb = (n + 63) >> 6;
     const int units = 4 * (nb * (nb + 1) / 2);
-    for (int u = wave; u < units; u += NT / 64) {
+    // one workgroup per image keeps the words in LDS; several write them to the workspace, and the last one to finish
+    // collects them
+    unsigned long long* mask = G == 1 ? s_mask : a.g_mask + (long long)b * PT_WORDS;
+#ifdef PT_SKIP_MASK
+    for (int i = tid; i < PT_WORDS; i += NT) s_mask[i] = 0ull;
+    for (int u = units; u < units; ++u) {
+#else
+    for (int u = (int)blockIdx.x * (NT / 64) + wave; u < units; u += G * (NT / 64)) {
+#endif
         int R = 0, rest = u >> 2;                  // tile -> (row block R, column block w), R <= w < nb
         while (rest >= nb - R) { rest -= nb - R; ++R; }
         const int w = R + rest;
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         const float aj = s_area[jv ? j : 0];
         const int r0 = 16 * (u & 3);
         const int pitch = PT_NB - R;
-        unsigned long long* out = s_mask + pt_block_base(R) + rest + r0 * pitch;
+        unsigned long long* out = mask + pt_block_base(R) + rest + r0 * pitch;
         const int i0 = 64 * R + r0;
         if (i0 >= n) continue;
 #pragma unroll
@@ -828,12 +848,32 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
             for (int k = 0; k < 4; ++k) {
                 const int i = i0 + q + k;
                 const unsigned long long word = __ballot(above[k] && jv && j > i);
-                if (lane == 0) out[(q + k) * pitch] = word;
+                if (lane == 0) {
+                    if (G == 1) out[(q + k) * pitch] = word;
+                    else __hip_atomic_store(out + (q + k) * pitch, word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
     }
+    PSTAMP(2);
+    if (G > 1) {
+        // The words travel as device-scope stores and loads (they pass the per-XCD L2s: the workgroups of an image run
+        // on different XCDs), and a wave has its stores acknowledged before the workgroup takes its ticket.  A
+        // device-scope fence pair instead (write-back and invalidation of whole L2s) was measured at 35 us.
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(&a.done[b], 1) == G - 1 ? 1 : 0;
+        __syncthreads();
+        if (!s_last) return;                       // the last workgroup of the image goes on alone
+        const int words = pt_block_base(nb);       // the row blocks in use, whole
+        for (int i = tid; i < words; i += NT)
+            s_mask[i] = __hip_atomic_load(mask + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     __syncthreads();
+    // the rescaled boxes go back in the given order (possibly over the input: every workgroup has read it by now)
+    if (a.scaled_boxes && tid < n) a.scaled_boxes[base + tid] = bx;
 
+    PSTAMP(3);
     // ---- 3. greedy walk over the blocks (one wave) -----------------------------------------------------------
     if (wave == 0) {
         unsigned long long pending = 0;            // lane w: suppression bits that kept rows left on block w
@@ -879,6 +919,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         if (lane == 0) { s_pre[nb] = nk; a.out_count[b] = nk; }
     }
     __syncthreads();
+    PSTAMP(4);
     // ---- 4. outputs: kept rows in order, zeros past the count --------------------------------------------------
     const int nk = s_pre[nb];
     if (tid < n) {
@@ -899,6 +940,12 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         a.out_labels[base + k] = 0;
         if (a.keep_idx) a.keep_idx[base + k] = 0;
     }
+#ifdef PT_STAMPS
+    PSTAMP(5);
+    if (tid == 0 && b == 0)
+        printf("tail stamps (10 ns): order %llu mask %llu collect %llu walk %llu out %llu\n", pst[1] - pst[0], pst[2] - pst[1],
+               pst[3] - pst[2], pst[4] - pst[3], pst[5] - pst[4]);
+#endif
 }
 
 }  // namespace
@@ -1049,10 +1096,27 @@ extern "C" int od_pack_detections(const float* boxes, const float* scores, const
     return OD_OK;
 }
 
+// workgroups per image: about 24 units of 16 rows x 64 columns each (one and a half per wave)
+static int predict_tail_groups(int max_det) {
+    const int nb = (max_det + 63) / 64;
+    const int units = 4 * (nb * (nb + 1) / 2);
+    const int g = (units + 23) / 24;
+    return g < 1 ? 1 : (g > 16 ? 16 : g);
+}
+
+// workspace: done counters (int32 [batch]) | suppression words (uint64 [batch, PT_WORDS]) when an image is shared
+extern "C" size_t od_predict_tail_workspace_bytes(int32_t batch, int32_t max_det) {
+    if (batch < 0 || max_det < 0 || max_det > PT_MAX) return 0;
+    size_t bytes = nms_align256((size_t)batch * sizeof(int));
+    if (predict_tail_groups(max_det) > 1) bytes += nms_align256((size_t)batch * PT_WORDS * sizeof(unsigned long long));
+    return bytes > 0 ? bytes : 256;
+}
+
 extern "C" int od_predict_tail(const float* boxes, const float* scores, const int64_t* labels, const int32_t* counts,
                                const float* ratio, int32_t batch, int32_t max_det, double iou_threshold, int32_t mode,
                                float* scaled_boxes, int32_t* out_boxes, float* out_scores, int64_t* out_labels,
-                               int64_t* keep_idx, int32_t* out_count, void* stream) {
+                               int64_t* keep_idx, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                               void* stream) {
     if (batch < 0 || max_det < 0) return OD_ERR_ARG;
     if (batch == 0) return OD_OK;
     if (!counts || !out_count) return OD_ERR_ARG;
@@ -1079,6 +1143,17 @@ extern "C" int od_predict_tail(const float* boxes, const float* scores, const in
     a.out_labels = (long long*)out_labels;
     a.keep_idx = (long long*)keep_idx;
     a.out_count = out_count;
-    OD_LAUNCH_KERNEL(OD_KERNEL_PREDICT_TAIL, predict_tail_kernel, dim3((unsigned)batch), dim3(NT), 0, (hipStream_t)stream, a);
+    const int groups = predict_tail_groups(max_det);
+    a.done = nullptr;
+    a.g_mask = nullptr;
+    if (groups > 1) {
+        if (!workspace || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
+        if (workspace_bytes < od_predict_tail_workspace_bytes(batch, max_det)) return OD_ERR_WORKSPACE;
+        a.done = (int*)workspace;
+        a.g_mask = (unsigned long long*)((char*)workspace + nms_align256((size_t)batch * sizeof(int)));
+        OD_HIP(hipMemsetAsync(a.done, 0, sizeof(int) * (size_t)batch, (hipStream_t)stream));
+    }
+    OD_LAUNCH_KERNEL(OD_KERNEL_PREDICT_TAIL, predict_tail_kernel, dim3((unsigned)groups, (unsigned)batch), dim3(NT), 0,
+                     (hipStream_t)stream, a);
     return OD_OK;
 }

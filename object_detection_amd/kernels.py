@@ -509,10 +509,15 @@ def predict_tail(boxes: Tensor, scores: Tensor, labels: Tensor, counts: Tensor, 
     out_scores = torch.empty((B, D), dtype=torch.float32, device=dev)
     out_labels = torch.empty((B, D), dtype=torch.int64, device=dev)
     out_count = torch.empty((B,), dtype=torch.int32, device=dev)
-    rc = _C.lib().od_predict_tail(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _ptr(ratio), B, D,
-                                  float(iou_threshold), int(mode), _ptr(boxes if scale_in_place else None),
-                                  _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels), _ptr(keep_idx), _ptr(out_count),
-                                  _stream(dev))
+    lib = _C.lib()
+    nbytes = _ws_bytes.get(("tail", B, D))
+    if nbytes is None:
+        nbytes = _ws_bytes[("tail", B, D)] = lib.od_predict_tail_workspace_bytes(B, D)
+    ws = _workspace(dev, "tail", nbytes)
+    rc = lib.od_predict_tail(_ptr(boxes), _ptr(scores), _ptr(labels), _ptr(counts), _ptr(ratio), B, D,
+                             float(iou_threshold), int(mode), _ptr(boxes if scale_in_place else None),
+                             _ptr(out_boxes), _ptr(out_scores), _ptr(out_labels), _ptr(keep_idx), _ptr(out_count),
+                             _ptr(ws), ws.numel(), _stream(dev))
     _C.check(rc, "od_predict_tail")
     return keep_idx, out_boxes, out_scores, out_labels, out_count
 

@@ -9,6 +9,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from object_detection_amd import _C, kernels  # noqa: E402
+if os.environ.get("OD_LIB"):
+    _C.LIB_PATH = os.path.abspath(os.environ["OD_LIB"])
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 500
