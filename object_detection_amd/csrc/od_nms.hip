@@ -699,7 +699,8 @@ __global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ bo
 
 // ---- tail of the reference's prediction loop (object_detection/predict.py:70-76) for a whole batch -----------
 // Per image: boxes.mul_(ratio); keep = nms(boxes, scores, thr); boxes.to(int32)[keep], scores[keep], labels[keep].
-// One 1024-thread workgroup per image, at most PT_MAX detections (what postprocess_detections leaves: <= 1024).
+// 1024-thread workgroups, at most PT_MAX detections per image (what postprocess_detections leaves: <= 1024); one
+// workgroup per image up to 128 detections, above that up to 16 that share step 2 and leave the rest to the last one.
 //   1. every thread scales one box and finds its place in the stable descending score order (detections arrive
 //      sorted from batched_nms, which one neighbour comparison per thread confirms; otherwise every thread counts
 //      the keys above its own);
@@ -800,12 +801,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
     // one workgroup per image keeps the words in LDS; several write them to the workspace, and the last one to finish
     // collects them
     unsigned long long* mask = G == 1 ? s_mask : a.g_mask + (long long)b * PT_WORDS;
-#ifdef PT_SKIP_MASK
-    for (int i = tid; i < PT_WORDS; i += NT) s_mask[i] = 0ull;
-    for (int u = units; u < units; ++u) {
-#else
     for (int u = (int)blockIdx.x * (NT / 64) + wave; u < units; u += G * (NT / 64)) {
-#endif
         int R = 0, rest = u >> 2;                  // tile -> (row block R, column block w), R <= w < nb
         while (rest >= nb - R) { rest -= nb - R; ++R; }
         const int w = R + rest;
