@@ -711,10 +711,12 @@ __global__ __launch_bounds__(256) void pack_kernel(const float4* __restrict__ bo
 //      or-ed into the masks of the later blocks; kept detections are written in order as they are found.
 constexpr int PT_MAX = 1024;
 constexpr int PT_NB = PT_MAX / 64;
-constexpr int PT_WORDS = 64 * (PT_NB * (PT_NB + 1) / 2);     // words of the upper block triangle
-
-// first word of row block R (rows 64R .. 64R+63 hold the words of column blocks R .. PT_NB-1)
-__device__ __forceinline__ int pt_block_base(int R) { return 64 * (PT_NB * R - R * (R - 1) / 2); }
+// Row block R (rows 64R .. 64R+63) holds the words of column blocks R .. PT_NB-1, with an odd number of words per row:
+// the walk reads one row per lane, and an even pitch would put all 64 lanes on the same LDS banks.
+__host__ __device__ __forceinline__ constexpr int pt_pitch(int R) { return (PT_NB - R) | 1; }
+// first word of row block R = 64 * sum of the pitches of the blocks before it
+__host__ __device__ __forceinline__ constexpr int pt_block_base(int R) { return 64 * (PT_NB * R - R * (R - 1) / 2 + (R + 1) / 2); }
+constexpr int PT_WORDS = pt_block_base(PT_NB);               // words of the upper block triangle
 
 struct PredictTailArgs {
     const float4* boxes;        // [batch, max_det]
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         const float4 cj = s_box[jv ? j : 0];
         const float aj = s_area[jv ? j : 0];
         const int r0 = 16 * (u & 3);
-        const int pitch = PT_NB - R;
+        const int pitch = pt_pitch(R);
         unsigned long long* out = mask + pt_block_base(R) + rest + r0 * pitch;
         const int i0 = 64 * R + r0;
         if (i0 >= n) continue;
@@ -881,7 +883,7 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
             const uint32_t phi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(pending >> 32), c);
             unsigned long long alive = valid & ~(((unsigned long long)phi << 32) | plo);
             const int i = 64 * c + lane;
-            const int pitch = PT_NB - c;
+            const int pitch = pt_pitch(c);
             const unsigned long long* row = s_mask + pt_block_base(c) + lane * pitch;
             const bool iv = i < n;
             // the row's words for this and all later blocks are requested together
