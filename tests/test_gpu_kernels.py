@@ -951,3 +951,34 @@ def test_predict_tail_known_answers_and_limits(device):
         n = _C.OD_MAX_PREDICT_TAIL + 1
         kernels.predict_tail(torch.zeros((1, n, 4), device=device), torch.zeros((1, n), device=device),
                              torch.zeros((1, n), dtype=torch.int64, device=device), c[:1], r, 0.3)
+
+
+def test_predict_tail_workspace_contract(device):
+    """od_predict_tail through the raw C ABI: the workspace size grows with the detections per image once an image is
+    shared by several workgroups, a workspace that is too small or missing is refused (OD_ERR_WORKSPACE / OD_ERR_ARG)
+    and nothing is launched, sizes beyond the limit give 0 / OD_ERR_LIMIT."""
+    import ctypes
+    lib = _C.lib()
+    assert lib.od_predict_tail_workspace_bytes(4, 100) < lib.od_predict_tail_workspace_bytes(4, 500)
+    assert lib.od_predict_tail_workspace_bytes(4, _C.OD_MAX_PREDICT_TAIL + 1) == 0
+    B, D = 2, 500
+    f = lambda *shape: torch.zeros(shape, device=device)
+    boxes, scores, ratio = f(B, D, 4), f(B, D), torch.ones((B, 4), device=device)
+    boxes[..., 2:] = 10.0                               # every box is [0, 0, 10, 10]
+    labels = torch.zeros((B, D), dtype=torch.int64, device=device)
+    counts = torch.full((B,), D, dtype=torch.int32, device=device)
+    ob = torch.zeros((B, D, 4), dtype=torch.int32, device=device)
+    os_, ol, oc = f(B, D), labels.clone(), torch.full((B,), -5, dtype=torch.int32, device=device)
+    need = lib.od_predict_tail_workspace_bytes(B, D)
+    ws = torch.zeros((need,), dtype=torch.uint8, device=device)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    call = lambda wptr, wbytes, d=D: lib.od_predict_tail(p(boxes), p(scores), p(labels), p(counts), p(ratio), B, d, 0.3, 0,
+                                                         None, p(ob), p(os_), p(ol), None, p(oc), wptr, wbytes, None)
+    assert call(p(ws), need - 1) == -3
+    assert call(None, need) == -1
+    assert call(p(ws), need, _C.OD_MAX_PREDICT_TAIL + 1) == -2
+    torch.cuda.synchronize()
+    assert oc.tolist() == [-5, -5]                      # refused calls launched nothing
+    assert call(p(ws), need) == 0
+    torch.cuda.synchronize()
+    assert oc.tolist() == [1, 1]                        # 500 identical boxes: the first one suppresses the rest
