@@ -67,7 +67,7 @@ def match(r):
 def run(n_post, n_match, steps=200, prio=(0, 0)):
     global streams
     # exactly the streams of this configuration, created together: inference streams first
-    streams = [torch.cuda.Stream(dev, priority=prio[0]) for _ in range(n_post)] + [None] * (3 - n_post) + \
+    streams = [torch.cuda.Stream(dev, priority=prio[0]) for _ in range(n_post)] + [None] * (4 - n_post) + \
               [torch.cuda.Stream(dev, priority=prio[1]) for _ in range(n_match)]
 
     def step(i):
@@ -76,7 +76,7 @@ def run(n_post, n_match, steps=200, prio=(0, 0)):
             torch.cuda.set_stream(streams[i % n_post])
             (post_select_only if NO_NMS else post)(r)
         if n_match:
-            torch.cuda.set_stream(streams[3 + i % n_match])
+            torch.cuda.set_stream(streams[4 + i % n_match])
             match(r)
     for i in range(40):
         step(i)
@@ -95,7 +95,10 @@ for _ in range(3):
 print("library:", _C.LIB_PATH)
 for no_nms in (False, True):
     NO_NMS = no_nms
-    for n_post, n_match in ((0, 1), (0, 2), (1, 0), (3, 0), (1, 1), (2, 1), (3, 1), (2, 2)):
+    configs = ((0, 1), (0, 2), (1, 0), (3, 0), (1, 1), (2, 1), (3, 1), (2, 2))
+    if os.environ.get("OD_PROBE_CONFIGS"):             # e.g. "3x2,4x2,3x3"
+        configs = tuple(tuple(int(v) for v in c.split("x")) for c in os.environ["OD_PROBE_CONFIGS"].split(","))
+    for n_post, n_match in configs:
         if no_nms and n_post == 0:
             continue
         ms, host = run(n_post, n_match)
