@@ -1,5 +1,6 @@
 """Randomised parity run: the HIP entry points against the scalar C checker (oracle/od_oracle.c) on many random shapes
-and value distributions -- matching (ragged pyramids, GT counts 0 ... 600, tiny and huge boxes, duplicates), candidate
+and value distributions (and, within stated floating-point tolerances, the fused head losses against the torch
+restatement) -- matching (ragged pyramids, GT counts 0 ... 600, tiny and huge boxes, duplicates), candidate
 selection (level sizes 1 ... 300 000, 1 ... 91 classes, thresholds, K), batched NMS (both branches, both threshold
 rules, ties, duplicates) and the prediction tail.  Every failure prints the seed that reproduces it.
 Usage: python tools/fuzz_parity.py [seconds per section] [first seed]"""
@@ -250,8 +251,101 @@ def fuzz_fcos(seed):
     return None
 
 
+def fuzz_focal(seed):
+    """Fused classification loss, forward and backward, against sigmoid_focal_loss evaluated in fp64 (loss 1e-5
+    relative, gradient 1e-5 of its largest entry plus 1e-4 relative per element): class counts 1 ... 91, ragged sizes,
+    image strides that break 16-byte alignment, fp32 / fp16 / bf16 logits."""
+    from oracle import tv_reference as tv
+    gen = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    C = [1, 2, 3, 4, 5, 8, 20, 91][ri(0, 7)]
+    n = [ri(1, 40), ri(41, 3000), ri(3001, 20000)][ri(0, 2)]
+    B, M = ri(1, 3), ri(1, 12)
+    pad = ri(0, 7)
+    dtype = [torch.float32, torch.float32, torch.float16, torch.bfloat16][ri(0, 3)]
+    storage = (torch.randn((B, n * C + pad), generator=gen) * 2.0 - 2.0).to(dtype)
+    logits = storage[:, :n * C].view(B, n, C)
+    matched = torch.randint(-2, M, (B, n), generator=gen)
+    if B > 1:
+        matched[1] = torch.where(matched[1] >= 0, torch.full_like(matched[1], -1), matched[1])
+    labels = torch.randint(0, C, (B * M,), generator=gen)
+    offs = [b * M for b in range(B + 1)]
+    alpha, gamma = [(0.25, 2.0), (-1.0, 2.0), (0.6, 0.5), (0.25, 0.0)][ri(0, 3)]
+    x = logits.double().requires_grad_(True)
+    total = 0.0
+    for b in range(B):
+        t = torch.zeros((n, C), dtype=torch.float64)
+        fg = matched[b] >= 0
+        t[fg, labels[offs[b]:offs[b + 1]][matched[b][fg]]] = 1.0
+        valid = matched[b] != -2
+        total = total + tv.sigmoid_focal_loss(x[b][valid], t[valid], alpha=alpha, gamma=gamma, reduction="sum") / max(1, int(fg.sum()))
+    ref = total / B
+    ref.backward()
+    xd = storage.to(dev)[:, :n * C].view(B, n, C)
+    md, ld, od = matched.to(dev), labels.to(dev), kernels._device_ints(offs, dev)
+    loss, _, nfg = kernels.focal_loss_forward(xd, md, ld, od, alpha, gamma)
+    what = f"(C={C}, n={n}, B={B}, pad={pad}, {dtype}, alpha={alpha}, gamma={gamma})"
+    if nfg.cpu().tolist() != [int((matched[b] >= 0).sum()) for b in range(B)]:
+        return "foreground counts differ " + what
+    if abs(loss.item() - ref.item()) > 1e-5 * abs(ref.item()) + 1e-7:
+        return f"loss {loss.item()} vs {ref.item()} " + what
+    grad = kernels.focal_loss_backward(xd, md, ld, od, alpha, gamma, nfg, torch.ones((1,), device=dev)).cpu().float()
+    gr = x.grad.float()
+    rel = {torch.float32: 1e-4, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]      # one rounding of the stored gradient
+    # fp16 gradients of a long, sparsely matched image reach the subnormal range, where the stored value moves in
+    # steps of 2^-24
+    tol = 1e-5 * gr.abs().max() + rel * gr.abs() + (2.0 ** -24 if dtype is torch.float16 else 0.0)
+    if not bool(((grad - gr).abs() <= tol).all()):
+        return f"gradient off by {float((grad - gr).abs().max())} " + what
+    if not torch.equal(grad[matched == -2], torch.zeros_like(grad[matched == -2])):
+        return "gradient of ignored anchors is not zero " + what
+    return None
+
+
+def fuzz_boxloss(seed):
+    """Fused regression loss (giou / l1 / smooth_l1), forward and backward, against the fp32 torch restatement."""
+    from oracle import tv_reference as tv
+    gen = torch.Generator().manual_seed(seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=gen))
+    loss_type = ["giou", "l1", "smooth_l1"][ri(0, 2)]
+    n = [ri(1, 50), ri(51, 3000), ri(3001, 12000)][ri(0, 2)]
+    B, M = ri(1, 3), ri(1, 12)
+    shared = ri(0, 1) == 1
+    weights = (1.0, 1.0, 1.0, 1.0) if ri(0, 1) else (10.0, 10.0, 5.0, 5.0)
+    ub = lambda c: torch.cat([(xy := torch.rand((c, 2), generator=gen) * 900.0), xy + 8.0 + torch.rand((c, 2), generator=gen) * 192.0], dim=1)
+    anchors = ub(n) if shared else torch.stack([ub(n) for _ in range(B)])
+    gt = [ub(M) for _ in range(B)]
+    matched = torch.randint(-2, M, (B, n), generator=gen)
+    if B > 1:
+        matched[B - 1] = torch.where(matched[B - 1] >= 0, torch.full_like(matched[B - 1], -1), matched[B - 1])
+    reg = torch.randn((B, n, 4), generator=gen) * 0.5
+    reg[0, ::97, 2] = 5.0
+    coder = tv.BoxCoder(weights)
+    eps = float(torch.finfo(torch.float32).eps)
+    x = reg.clone().requires_grad_(True)
+    a_list = [(anchors if shared else anchors[b]) for b in range(B)]
+    ref = tv.retinanet_head_loss_regression([{"boxes": b} for b in gt], x, a_list, list(matched), loss_type, 0.3, coder, eps=eps)
+    ref.backward()
+    code = {"l1": _C.BOX_LOSS_L1, "smooth_l1": _C.BOX_LOSS_SMOOTH_L1, "giou": _C.BOX_LOSS_GIOU}[loss_type]
+    conf = (code, 0.3, weights, coder.bbox_xform_clip, eps)
+    rd, ad, md = reg.to(dev), anchors.to(dev), matched.to(dev)
+    gd, od = torch.cat(gt).to(dev), kernels._device_ints([b * M for b in range(B + 1)], dev)
+    loss, _, nfg = kernels.box_loss_forward(rd, ad, md, gd, od, *conf)
+    what = f"({loss_type}, n={n}, B={B}, M={M}, shared={shared}, weights={weights})"
+    if abs(loss.item() - ref.item()) > 1e-5 * abs(ref.item()) + 1e-7:
+        return f"loss {loss.item()} vs {ref.item()} " + what
+    grad = kernels.box_loss_backward(rd, ad, md, gd, od, *conf, nfg, torch.full((1,), 2.0, device=dev)).cpu()
+    gr = 2.0 * x.grad
+    tol = 1e-5 * gr.abs().max() + 1e-4 * gr.abs()
+    if not bool(((grad - gr).abs() <= tol).all()):
+        return f"gradient off by {float((grad - gr).abs().max())} " + what
+    if not torch.equal(grad[matched < 0], torch.zeros_like(grad[matched < 0])):
+        return "gradient of anchors that are not foreground is not zero " + what
+    return None
+
+
 SECTIONS = (("match", fuzz_match), ("select", fuzz_select), ("nms", fuzz_nms), ("nms_segments", fuzz_nms_segments),
-            ("fcos", fuzz_fcos), ("tail", fuzz_tail))
+            ("fcos", fuzz_fcos), ("tail", fuzz_tail), ("focal", fuzz_focal), ("boxloss", fuzz_boxloss))
 
 
 def run_seeds(name, seeds):
