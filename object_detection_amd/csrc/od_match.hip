@@ -654,6 +654,11 @@ constexpr int ZB = 8;
 #define OD_RT 256
 #endif
 constexpr int RT = OD_RT;      // threads of a restore block
+#ifndef OD_LSTEP
+#define OD_LSTEP 8
+#endif
+constexpr int LSTEP = OD_LSTEP;  // entry slots that get blocks of their own; a block goes on to slot e + LSTEP while its tiles have that many entries
+static_assert(LCAP % LSTEP == 0, "the restore kernel walks the entry slots in steps of LSTEP");
 __global__ __launch_bounds__(RT) void match_restore_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, TileLayout layout,
     int batch, int light_blocks, int heavy_blocks, int heavy_first, const float4* __restrict__ gt,
@@ -701,13 +706,14 @@ __global__ __launch_bounds__(RT) void match_restore_kernel(
     }
     // Heavy entries: consecutive entries belong to one tile and often hit together, so they are dealt to different
     // waves (entry = lane * waves + wave); light entries are slot-major already.
-    // A light block takes 256 neighbouring tiles at one entry slot e < HEAVY (block -> slot and tile range by a scalar
-    // division, nothing per thread): items = HEAVY * tile_blocks, dealt to the light blocks in turn.  The slots from
-    // HEAVY on are only filled by tiles of images with more than DENSE_GT boxes: the block goes on to slot e + HEAVY
-    // if one of its tiles has that many entries.
+    // A light block takes 256 neighbouring tiles at one entry slot e < LSTEP (block -> slot and tile range by a scalar
+    // division, nothing per thread): items = LSTEP * tile_blocks, dealt to the light blocks in turn.  Most tiles have
+    // fewer than LSTEP entries; a block goes on to slot e + LSTEP (and so on, up to LCAP) while one of its tiles has
+    // that many.  (With a block for every slot below HEAVY two thirds of the blocks found nothing to do: the kernel
+    // took the same time alone, but its waves stood in the way of the other streams' kernels.)
     const long long nwaves = nthreads >> 6, wave_id = first >> 6;
     const long long tile_blocks = (total + RT - 1) / RT;
-    const long long light_items = tile_blocks * HEAVY;
+    const long long light_items = tile_blocks * LSTEP;
     for (long long k0 = 0; light ? (k0 + lb < light_items) : (k0 < limit); k0 += light ? (long long)light_blocks : nthreads) {
         int pass = 0, more = 0;
         do {
@@ -716,7 +722,7 @@ __global__ __launch_bounds__(RT) void match_restore_kernel(
             bool have = false;
             if (light) {                                     // slot-major: neighbouring threads, neighbouring tiles
                 const uint32_t item = (uint32_t)(k0 + lb);                  // < HEAVY * 2^23: 32-bit division
-                const int e = (int)(item / (uint32_t)tile_blocks) + pass * HEAVY;
+                const int e = (int)(item / (uint32_t)tile_blocks) + pass * LSTEP;
                 const long long tile = (long long)(item % (uint32_t)tile_blocks) * RT + threadIdx.x;
                 if (tile < total) {
                     wslot = (int)tile;
@@ -729,7 +735,7 @@ __global__ __launch_bounds__(RT) void match_restore_kernel(
                     }
                 }
                 ++pass;
-                more = (pass < LCAP / HEAVY) ? __syncthreads_or(my_count > e + HEAVY ? 1 : 0) : 0;
+                more = (pass < LCAP / LSTEP) ? __syncthreads_or(my_count > e + LSTEP ? 1 : 0) : 0;
             } else {
                 const long long i = k0 + (long long)lane * nwaves + wave_id;
                 if (i < limit) {
@@ -1083,7 +1089,7 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                          (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
     }
     if (restore) {
-        const long long light_items = ((total_tiles + RT - 1) / RT) * HEAVY;      // (entry slot below HEAVY, 256 tiles)
+        const long long light_items = ((total_tiles + RT - 1) / RT) * LSTEP;      // (entry slot below LSTEP, 256 tiles)
         const int light_blocks = (int)(light_items < 16384 ? light_items : 16384);
         const int heavy_entry_blocks = m_total > HEAVY ? batch * (512 / batch > 1 ? 512 / batch : 1) : 0;
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_kernel,
