@@ -68,6 +68,18 @@ def main():
             out[f"{k}{i}"] = d[k].numpy()
     np.savez_compressed(os.path.join(OUT, "postprocess_small.npz"), **out)
 
+    # tail of the reference's prediction loop (predict.py:66-76) on the detections above: rescale to the size of the
+    # original image, class-agnostic NMS at 0.3 under both threshold rules, int32 boxes
+    tail = dict(image_wh=np.asarray([(1920, 1080), (100, 161)]), model_wh=np.asarray((128, 128)))
+    for i, d in enumerate(dets):
+        for rule, float_rule in (("cuda", True), ("cpu", False)):
+            pred = {k: d[k].clone() for k in ("boxes", "scores", "labels")}
+            tb, ts, tl, tk = tv.predict_tail(pred, tuple(int(v) for v in tail["image_wh"][i]), (128, 128), 0.3, float_rule)
+            tail[f"boxes{i}_{rule}"], tail[f"scores{i}_{rule}"] = tb.numpy(), ts.numpy()
+            tail[f"labels{i}_{rule}"], tail[f"keep{i}_{rule}"] = tl.numpy(), tk.numpy()
+            tail[f"scaled{i}"] = pred["boxes"].numpy()
+    np.savez_compressed(os.path.join(OUT, "predict_tail_small.npz"), **tail)
+
     x = np.concatenate([np.linspace(-104, 89, 4001), [-200.0, 100.0, 0.0, math.log(1000 / 16)]]).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, "spec_math.npz"), x=x, exp=c_oracle.expf(x), sigmoid=c_oracle.sigmoidf(x))
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

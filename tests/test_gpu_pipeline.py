@@ -803,3 +803,28 @@ def test_random_shapes_against_the_scalar_checker(device, section, cases):
     spec.loader.exec_module(fuzz)
     bad = fuzz.run_seeds(section, range(1000, 1000 + cases))
     assert not bad, bad[:3]
+
+
+def test_predict_tail_golden_fixture(device):
+    """od_predict_tail on the detections of the postprocess fixture against tests/golden/predict_tail_small.npz."""
+    g = np.load(os.path.join(GOLD, "predict_tail_small.npz"))
+    p = np.load(os.path.join(GOLD, "postprocess_small.npz"))
+    D = max(p["boxes0"].shape[0], p["boxes1"].shape[0])
+    pad = lambda a, shape, dt: torch.from_numpy(np.concatenate([a, np.zeros((D - a.shape[0],) + shape, dtype=a.dtype)])).to(dt)
+    boxes = torch.stack([pad(p[f"boxes{i}"], (4,), torch.float32) for i in range(2)]).to(device)
+    scores = torch.stack([pad(p[f"scores{i}"], (), torch.float32) for i in range(2)]).to(device)
+    labels = torch.stack([pad(p[f"labels{i}"], (), torch.int64) for i in range(2)]).to(device)
+    counts = torch.tensor([p["boxes0"].shape[0], p["boxes1"].shape[0]], dtype=torch.int32, device=device)
+    mw, mh = (int(v) for v in g["model_wh"])
+    ratio = torch.tensor([[w / mw, h / mh] * 2 for w, h in g["image_wh"].tolist()], dtype=torch.float32, device=device)
+    for rule, mode in (("cuda", _C.NMS_THRESHOLD_FLOAT), ("cpu", 0)):
+        b = boxes.clone()
+        keep, ob, os_, ol, oc = kernels.predict_tail(b, scores, labels, counts, ratio, 0.3, mode)
+        for i in range(2):
+            k = int(oc[i])
+            assert k == g[f"keep{i}_{rule}"].shape[0]
+            assert np.array_equal(keep[i, :k].cpu().numpy(), g[f"keep{i}_{rule}"])
+            assert np.array_equal(ob[i, :k].cpu().numpy(), g[f"boxes{i}_{rule}"])
+            assert np.array_equal(os_[i, :k].cpu().numpy(), g[f"scores{i}_{rule}"])
+            assert np.array_equal(ol[i, :k].cpu().numpy(), g[f"labels{i}_{rule}"])
+            assert np.array_equal(b[i, :int(counts[i])].cpu().numpy(), g[f"scaled{i}"])

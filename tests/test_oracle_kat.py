@@ -219,3 +219,26 @@ def test_predict_tail_restatements_agree():
     assert k.tolist() == [0, 2] and b.tolist() == [[0, 0, 10, 10], [20, 20, 30, 30]] and l.tolist() == [1, 3]
     _, _, _, k = tv.predict_tail({k_: v.clone() for k_, v in kat.items()}, (512, 512), (1024, 1024), 0.3, True)
     assert k.tolist() == [0, 1, 2]
+
+
+def test_predict_tail_golden_fixture_matches_oracle():
+    """tests/golden/predict_tail_small.npz (made by tests/golden/make_golden.py from the detections of
+    postprocess_small.npz): both restatements of reference predict.py:66-76 reproduce it."""
+    import numpy as np
+    import torch
+    from oracle import c_oracle, tv_reference as tv
+    g = np.load(os.path.join(GOLD, "predict_tail_small.npz"))
+    p = np.load(os.path.join(GOLD, "postprocess_small.npz"))
+    model_wh = tuple(int(v) for v in g["model_wh"])
+    for i in range(2):
+        wh = tuple(int(v) for v in g["image_wh"][i])
+        for rule, float_rule in (("cuda", True), ("cpu", False)):
+            pred = {k: torch.from_numpy(p[f"{k}{i}"].copy()) for k in ("boxes", "scores", "labels")}
+            tb, ts, tl, tk = tv.predict_tail(pred, wh, model_wh, 0.3, float_rule)
+            assert np.array_equal(tk.numpy(), g[f"keep{i}_{rule}"]) and np.array_equal(tb.numpy(), g[f"boxes{i}_{rule}"])
+            assert np.array_equal(ts.numpy(), g[f"scores{i}_{rule}"]) and np.array_equal(tl.numpy(), g[f"labels{i}_{rule}"])
+            assert np.array_equal(pred["boxes"].numpy(), g[f"scaled{i}"])
+            ratio = np.array([wh[0] / model_wh[0], wh[1] / model_wh[1]] * 2, dtype=np.float32)
+            ck = c_oracle.nms(p[f"boxes{i}"] * ratio, p[f"scores{i}"], 0.3, float_rule)
+            assert np.array_equal(ck, g[f"keep{i}_{rule}"])
+        assert 0 < len(g[f"keep{i}_cuda"]) < p[f"boxes{i}"].shape[0]          # the second NMS removes something
