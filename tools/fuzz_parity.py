@@ -337,8 +337,16 @@ def fuzz_boxloss(seed):
     grad = kernels.box_loss_backward(rd, ad, md, gd, od, *conf, nfg, torch.full((1,), 2.0, device=dev)).cpu()
     gr = 2.0 * x.grad
     tol = 1e-5 * gr.abs().max() + 1e-4 * gr.abs()
-    if not bool(((grad - gr).abs() <= tol).all()):
-        return f"gradient off by {float((grad - gr).abs().max())} " + what
+    wrong = (grad - gr).abs() > tol
+    if loss_type == "l1" and bool(wrong.any()):
+        # the l1 gradient is the sign of (regression - encoded target): where the two agree to the last bits the sign
+        # hangs on the rounding of the encoder's logarithm, and either answer is a subgradient
+        for b, a, c in wrong.nonzero().tolist():
+            t = coder.encode_single(gt[b][matched[b, a]][None], a_list[b][a][None])[0, c]
+            if abs(float(reg[b, a, c] - t)) <= 4e-7 * max(1.0, abs(float(t))):
+                wrong[b, a, c] = False
+    if bool(wrong.any()):
+        return f"gradient off by {float((grad - gr).abs()[wrong].max())} " + what
     if not torch.equal(grad[matched < 0], torch.zeros_like(grad[matched < 0])):
         return "gradient of anchors that are not foreground is not zero " + what
     return None
