@@ -141,6 +141,7 @@ _COUNT_ROWS = 64                    # pinned rows for detection counts on their 
 _count_pool: Dict[int, Tensor] = {}  # batch size -> pinned int32 [_COUNT_ROWS, batch]
 _count_owner: Dict[tuple, "weakref.ref"] = {}
 _count_next: Dict[int, int] = {}
+_count_events: Dict[tuple, list] = {}  # (device, batch size) -> one event per pinned row
 
 
 class _PendingBatch:
@@ -164,7 +165,11 @@ class _PendingBatch:
         _count_owner[(B, row)] = weakref.ref(self)
         self.counts_host = pool[row]
         self.counts_host.copy_(counts_dev, non_blocking=True)
-        self.event = torch.cuda.Event()
+        # one event per pinned row, recorded again at every reuse (the row's previous batch has been read out above)
+        events = _count_events.setdefault((counts_dev.device.index, B), [None] * _COUNT_ROWS)
+        if events[row] is None:
+            events[row] = torch.cuda.Event()
+        self.event = events[row]
         self.event.record()
         self._counts = None
         self._rows = None
