@@ -132,9 +132,20 @@ def _shared_levels(anchors: List[List[Tensor]]) -> Optional[List[Tensor]]:
     return list(first)
 
 
+_hw_tables: Dict[tuple, Tensor] = {}
+
+
 def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) -> Tensor:
-    flat = [int(v) for hw in image_shapes for v in hw]
-    return kernels._device_ints(flat, device).view(-1, 2)
+    """int32 [B, 2] (height, width) on the device; looked up by the shapes themselves (a training or prediction loop
+    passes the same list of sizes step after step)."""
+    key = (device.index, kernels._raw_stream(device), tuple(image_shapes))
+    t = _hw_tables.get(key)
+    if t is None:
+        if len(_hw_tables) > 256:
+            _hw_tables.clear()
+        flat = [int(v) for hw in image_shapes for v in hw]
+        t = _hw_tables[key] = kernels._device_ints(flat, device).view(-1, 2)
+    return t
 
 
 _COUNT_ROWS = 64                    # pinned rows for detection counts on their way to the host
