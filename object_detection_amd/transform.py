@@ -46,15 +46,14 @@ class GeneralizedRCNNTransform(nn.Module):
         self.fixed_size = fixed_size
 
     def _resized_size(self, h: int, w: int) -> Tuple[int, int]:
-        """Size torchvision's ``resize`` gives an h x w image.  Its scale factor is the smaller of ``min_size / short
-        side`` and ``max_size / long side`` with the sides as fp32 tensors; a Python number divided by a tensor is
-        evaluated by torch as reciprocal(tensor) * number, two fp32 roundings (97 / 97 gives 0.99999994, and the
-        image shrinks by a pixel).  ``interpolate`` then takes floor(size * scale) in double arithmetic."""
+        """Size torchvision's ``resize`` gives an h x w image in eager mode (what the reference's train.py and
+        predict.py run): the scale factor is the smaller of ``min_size / short side`` and ``max_size / long side`` in
+        Python floats (doubles) -- only the scripted / traced branch of ``_resize_image_and_masks`` forms it from fp32
+        tensors.  ``interpolate(recompute_scale_factor=True)`` then takes floor(size * scale) in double arithmetic:
+        64 / 100 keeps 64 rows and 97 / 97 keeps 97."""
         if self.fixed_size is not None:
             return int(self.fixed_size[1]), int(self.fixed_size[0])
-        one = np.float32(1.0)
-        scale = float(min((one / np.float32(min(h, w))) * np.float32(self.min_size[-1]),
-                          (one / np.float32(max(h, w))) * np.float32(self.max_size)))
+        scale = min(float(self.min_size[-1]) / float(min(h, w)), float(self.max_size) / float(max(h, w)))
         return int(math.floor(float(h) * scale)), int(math.floor(float(w) * scale))
 
     def forward(self, images: List[Tensor], targets: Optional[List[Dict[str, Tensor]]] = None):

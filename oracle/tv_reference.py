@@ -542,18 +542,20 @@ def resize_boxes(boxes: Tensor, original_size: Sequence[int], new_size: Sequence
     return torch.stack((xmin, ymin, xmax, ymax), dim=1)
 
 
-def _resize_image(image: Tensor, self_min_size: int, self_max_size: int, fixed_size=None) -> Tensor:
-    im_shape = torch.tensor(image.shape[-2:])
+def _resize_image(image: Tensor, self_min_size: float, self_max_size: float, fixed_size=None) -> Tensor:
+    """``_resize_image_and_masks`` in eager mode: ``im_shape = image.shape[-2:]`` and the scale factor in Python floats
+    ("the normal way"); the fp32-tensor arithmetic belongs to the scripted / traced branch, which the reference's
+    train.py / predict.py never take."""
+    im_shape = image.shape[-2:]
     size = None
     scale_factor = None
     recompute_scale_factor = None
     if fixed_size is not None:
         size = [fixed_size[1], fixed_size[0]]
     else:
-        min_size = torch.min(im_shape).to(dtype=torch.float32)
-        max_size = torch.max(im_shape).to(dtype=torch.float32)
-        scale = torch.min(self_min_size / min_size, self_max_size / max_size)
-        scale_factor = scale.item()
+        min_size = min(im_shape)
+        max_size = max(im_shape)
+        scale_factor = min(self_min_size / min_size, self_max_size / max_size)
         recompute_scale_factor = True
     return torch.nn.functional.interpolate(image[None], size=size, scale_factor=scale_factor, mode="bilinear",
                                            recompute_scale_factor=recompute_scale_factor, align_corners=False)[0]

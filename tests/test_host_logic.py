@@ -100,7 +100,7 @@ def test_transform_resize_rules_on_host():
     tg = [{"boxes": torch.tensor([[10., 20., 40., 60.]]), "labels": torch.tensor([1])},
           {"boxes": torch.tensor([[3, 7, 41, 33]]), "labels": torch.tensor([2])}]
     _, ref_sizes, ref_t = ref.forward(imgs, tg)
-    assert ref_sizes[0] == (63, 51)                              # scale = fp32(64) / fp32(100) = 0.63999998...
+    assert ref_sizes[0] == (64, 51)                              # scale = 64 / 100 in Python floats (eager branch)
     from object_detection_amd import transform as T
     for t, rt, im, new in zip(tg, ref_t, imgs, ref_sizes):
         assert tr._resized_size(*im.shape[-2:]) == new
@@ -139,6 +139,12 @@ def test_transform_host_size_and_ratio_rules():
     for h, w in [(100, 80), (50, 90), (333, 77), (97, 131), (640, 480), (31, 1000)]:
         want = tuple(ref.resize(torch.zeros(3, h, w), None)[0].shape[-2:])
         assert tr._resized_size(h, w) == want, (h, w)
+    assert tr._resized_size(97, 131) == (97, 131)          # 97 / 97 = 1.0 exactly in doubles: nothing shrinks
+    square = GeneralizedRCNNTransform(1312, 1312, [0.5] * 3, [0.25] * 3)
+    for s in (1312, 1504, 1760):                           # sizes whose fp32 reciprocal * size falls below 1
+        one = GeneralizedRCNNTransform(s, s, [0.5] * 3, [0.25] * 3)
+        assert one._resized_size(s, s) == (s, s)
+    assert square._resized_size(640, 480) == (1312, 983)   # 480 * (1312 / 640) = 983.9999999999999 in doubles
     boxes = torch.tensor([[3.0, 7.0, 40.5, 91.25], [0.0, 0.0, 1.0, 1.0]])
     for old, new in [((100, 80), (64, 51)), ((333, 77), (97, 22)), ((97, 131), (97, 131))]:
         ratios = [torch.tensor(s, dtype=torch.float32) / torch.tensor(o, dtype=torch.float32) for s, o in zip(new, old)]
