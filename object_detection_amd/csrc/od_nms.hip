@@ -858,6 +858,14 @@ __global__ __launch_bounds__(NT) void predict_tail_kernel(PredictTailArgs a) {
         // The words travel as device-scope stores and loads (they pass the per-XCD L2s: the workgroups of an image run
         // on different XCDs), and a wave has its stores acknowledged before the workgroup takes its ticket.  A
         // device-scope fence pair instead (write-back and invalidation of whole L2s) was measured at 35 us.
+        // This is NOT the release / acquire pairing of the HIP memory model; it relies on what gfx942 / gfx950 do:
+        // an agent-scope store is issued with sc1 and written through the XCD's L2 to memory, vector stores are
+        // counted by vmcnt on these targets (s_waitcnt 0 returns once they are acknowledged), the ticket is a
+        // memory-side atomic, and an agent-scope load misses the reader's L2.  A target that counts stores
+        // elsewhere (vscnt on gfx10+) needs the wait changed, hence the guard.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "predict_tail_kernel's cross-workgroup hand-off is written for gfx942 / gfx950 (see the comment above)"
+#endif
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
         if (tid == 0) s_last = atomicAdd(&a.done[b], 1) == G - 1 ? 1 : 0;

@@ -38,8 +38,9 @@ class Matcher:
 
 
 class BoxCoder:
-    """Centre/size delta coding.  ``decode_single`` without autograd runs the HIP kernel (specified
-    fp32 exp); when gradients are required it runs the same formulas as PyTorch ops."""
+    """Centre/size delta coding.  ``decode_single`` runs the HIP kernel (specified fp32 exp) and builds no autograd
+    graph: inputs that require a gradient are rejected (the differentiable decode of torchvision's ``_box_loss`` lives
+    in the fused loss kernels)."""
 
     def __init__(self, weights: Tuple[float, float, float, float], bbox_xform_clip: float = math.log(1000.0 / 16)):
         self.weights = weights

@@ -15,7 +15,12 @@ What makes a step safe to capture (and what ``capture`` arranges):
   * the step must not make the host wait for the GPU and must not read device values on the host: use the padded
     forms (``postprocess_batched(..., return_padded=True)``), not the per-image ``Detections`` lists;
   * shapes are frozen: the inputs of a replay are the tensors that were captured (copy new values into them), and the
-    number of GT boxes per image is part of the recorded launch arguments.
+    number of GT boxes per image is part of the recorded launch arguments;
+  * the recorded launches hold raw addresses of those cached tables and scratch buffers, while the caches drop entries
+    on their own schedule (the table cache is cleared when it is full -- a training loop whose GT counts change every
+    step fills it --, a scratch buffer is replaced when a later call needs a larger one).  ``capture`` therefore
+    collects every cached tensor the launchers hand out while the step is recorded and the ``CapturedStep`` keeps them
+    alive for as long as the graph lives.
 """
 from __future__ import annotations
 
@@ -23,16 +28,17 @@ from typing import Any, Callable, Sequence, Tuple
 
 import torch
 
-from . import _C
+from . import _C, kernels
 
 
 class CapturedStep:
     """A recorded step: ``replay()`` enqueues it on the current stream, ``outputs`` are its static output tensors."""
 
-    def __init__(self, graph: "torch.cuda.CUDAGraph", outputs: Any, stream: "torch.cuda.Stream"):
+    def __init__(self, graph: "torch.cuda.CUDAGraph", outputs: Any, stream: "torch.cuda.Stream", held: Sequence[Any] = ()):
         self.graph = graph
         self.outputs = outputs
         self.capture_stream = stream
+        self.held = tuple(held)        # cached tables / scratch buffers whose addresses the recorded launches use
 
     def replay(self) -> Any:
         self.graph.replay()
@@ -55,6 +61,11 @@ def capture(step: Callable[[], Any], device: torch.device, warmup: int = 3,
     for s in side_streams:
         s.synchronize()
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph, stream=stream):
-        outputs = step()
-    return CapturedStep(graph, outputs, stream)
+    previous, kernels._capture_refs = kernels._capture_refs, []
+    try:
+        with torch.cuda.graph(graph, stream=stream):
+            outputs = step()
+        held = kernels._capture_refs
+    finally:
+        kernels._capture_refs = previous
+    return CapturedStep(graph, outputs, stream, held)

@@ -17,6 +17,17 @@ from . import _C
 _workspaces: Dict[tuple, Tensor] = {}
 _small_cache: Dict[tuple, Tensor] = {}
 _ws_bytes: Dict[tuple, int] = {}     # answers of the *_workspace_bytes queries (pure functions of the sizes)
+# While a step is being recorded into a HIP graph (graph_step.capture) this is a list that receives every cached
+# tensor the launchers hand to a kernel -- uploaded tables, scratch buffers, reusable candidate buffers.  The recorded
+# launches hold raw addresses of them, and the caches above drop entries on their own schedule (the table cache is
+# cleared when it is full, a scratch buffer is replaced by a larger one): the graph keeps its own references.
+_capture_refs: Optional[list] = None
+
+
+def _held(t):
+    if _capture_refs is not None:
+        _capture_refs.append(t)
+    return t
 
 
 def _require_gpu(t: Tensor, name: str) -> None:
@@ -50,7 +61,7 @@ def _workspace(device: torch.device, tag: str, nbytes: int) -> Tensor:
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
-    return ws
+    return _held(ws)
 
 
 def _f32c(t: Tensor) -> Tensor:
@@ -83,7 +94,7 @@ def _device_ints(values: Sequence[int], device: torch.device, dtype=torch.int32)
         # everything queued on the stream (per step, when the GT counts change every step)
         t = _upload(torch.tensor(list(key[3]), dtype=dtype), device)
         _small_cache[key] = t
-    return t
+    return _held(t)
 
 
 def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
@@ -100,7 +111,7 @@ def _device_floats(values: Sequence[float], device: torch.device) -> Tensor:
             _pinned_sources.clear()
         t = _upload(torch.tensor(list(vals), dtype=torch.float32), device)
         _small_cache[key] = t
-    return t
+    return _held(t)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -281,7 +292,7 @@ def _candidate_outputs(dev: torch.device, B: int, L: int, K: int, want_index: bo
     if key is not None:
         bufs = _candidate_buffers.get(key)
         if bufs is not None:
-            return bufs
+            return _held(bufs)
     bufs = (torch.empty((B, L * K, 4), dtype=torch.float32, device=dev),
             torch.empty((B, L * K), dtype=torch.float32, device=dev),
             torch.empty((B, L * K), dtype=torch.int32, device=dev),
@@ -291,7 +302,7 @@ def _candidate_outputs(dev: torch.device, B: int, L: int, K: int, want_index: bo
         if len(_candidate_buffers) > 64:
             _candidate_buffers.clear()
         _candidate_buffers[key] = bufs
-    return bufs
+    return _held(bufs)
 
 
 def select_candidates(cls_levels: Sequence[Tensor], reg_levels: Sequence[Tensor], anchor_levels: Sequence[Tensor],

@@ -12,6 +12,7 @@ forward / backward kernels.
 from __future__ import annotations
 
 import math
+import threading
 import weakref
 from collections import OrderedDict
 from typing import Callable, Dict, List, Optional, Tuple
@@ -145,7 +146,7 @@ def _image_hw_tensor(image_shapes: List[Tuple[int, int]], device: torch.device) 
             _hw_tables.clear()
         flat = [int(v) for hw in image_shapes for v in hw]
         t = _hw_tables[key] = kernels._device_ints(flat, device).view(-1, 2)
-    return t
+    return kernels._held(t)
 
 
 _COUNT_ROWS = 64                    # pinned rows for detection counts on their way to the host
@@ -153,6 +154,7 @@ _count_pool: Dict[int, Tensor] = {}  # batch size -> pinned int32 [_COUNT_ROWS, 
 _count_owner: Dict[tuple, "weakref.ref"] = {}
 _count_next: Dict[int, int] = {}
 _count_events: Dict[tuple, list] = {}  # (device, batch size) -> one event per pinned row
+_count_lock = threading.Lock()         # the hand-out of pinned rows: two threads must not receive the same row
 
 
 class _PendingBatch:
@@ -164,16 +166,17 @@ class _PendingBatch:
     def __init__(self, boxes: Tensor, scores: Tensor, labels: Tensor, counts_dev: Tensor):
         self.boxes, self.scores, self.labels, self.counts_dev = boxes, scores, labels, counts_dev
         B = int(counts_dev.shape[0])
-        pool = _count_pool.get(B)
-        if pool is None:
-            pool = _count_pool[B] = torch.empty((_COUNT_ROWS, B), dtype=torch.int32).pin_memory()
-        row = _count_next.get(B, 0)
-        _count_next[B] = (row + 1) % _COUNT_ROWS
-        previous = _count_owner.get((B, row))
+        with _count_lock:
+            pool = _count_pool.get(B)
+            if pool is None:
+                pool = _count_pool[B] = torch.empty((_COUNT_ROWS, B), dtype=torch.int32).pin_memory()
+            row = _count_next.get(B, 0)
+            _count_next[B] = (row + 1) % _COUNT_ROWS
+            previous = _count_owner.get((B, row))
+            _count_owner[(B, row)] = weakref.ref(self)
         previous = previous() if previous is not None else None
         if previous is not None:
             previous.counts()
-        _count_owner[(B, row)] = weakref.ref(self)
         self.counts_host = pool[row]
         self.counts_host.copy_(counts_dev, non_blocking=True)
         # one event per pinned row, recorded again at every reuse (the row's previous batch has been read out above)
@@ -325,6 +328,43 @@ class Detections(dict):
     def copy(self):
         self._materialize()
         return dict.copy(self)
+
+    def __ne__(self, other):
+        self._materialize()
+        return dict.__ne__(self, other)
+
+    def __delitem__(self, key):
+        self._materialize()
+        dict.__delitem__(self, key)
+
+    def __reversed__(self):
+        self._materialize()
+        return dict.__reversed__(self)
+
+    def __or__(self, other):
+        self._materialize()
+        return dict.__or__(self, other)
+
+    def __ror__(self, other):
+        self._materialize()
+        return dict.__ror__(self, other)
+
+    def __ior__(self, other):
+        self._materialize()
+        dict.update(self, other)
+        return self
+
+    def setdefault(self, key, default=None):
+        self._materialize()
+        return dict.setdefault(self, key, default)
+
+    def popitem(self):
+        self._materialize()
+        return dict.popitem(self)
+
+    def clear(self):
+        self._materialize()
+        dict.clear(self)
 
 
 def postprocess_batched(cls_levels, reg_levels, anchors, image_shapes, score_thresh, topk_candidates, nms_thresh,

@@ -47,8 +47,8 @@ def _exchange(local: Tensor, gathered: Optional[Tensor], group) -> Tensor:
         gathered = local.new_empty((world * local.shape[0], local.shape[1]))
     try:
         dist.all_gather_into_tensor(gathered, local, group=group)
-    except (RuntimeError, NotImplementedError):   # backends without the flat form
-        parts = [torch.empty_like(local) for _ in range(world)]
+    except NotImplementedError:                   # a backend without the flat form; any other error (a failed RCCL
+        parts = [torch.empty_like(local) for _ in range(world)]    # collective, a shape mismatch) is the caller's to see
         dist.all_gather(parts, local, group=group)
         gathered = torch.cat(parts)
     return gathered.to(device) if staged else gathered

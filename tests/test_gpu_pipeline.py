@@ -589,6 +589,36 @@ def test_graph_capture_replays_step(device):
             for a, b, name in zip(got, want[i], ("boxes", "scores", "labels", "counts", "matched")):
                 assert torch.equal(a, b), (rep, i, name)
     assert int(want[0][3].min()) > 0 and not torch.equal(want[0][4], want[1][4])
+    # The launchers' caches move on behind the graph's back: the table cache is cleared (a loop whose GT counts change
+    # every step fills it), the scratch buffers of the capture streams are replaced by larger ones, and the freed
+    # memory is handed to somebody else.  The graph holds its own references and replays the same results.
+    assert len(captured.held) > 0
+    for st in (captured.capture_stream, side):
+        with torch.cuda.stream(st):
+            for j in range(4200):
+                kernels._device_ints((j, j + 1, 7), device)
+            for tag in ("match", "select", "nms"):
+                kernels._workspace(device, tag, 1 << 28)
+    assert len(kernels._small_cache) < 4200                        # the cache was cleared on the way
+    from object_detection_amd import retinanet as rn
+    rn._hw_tables.clear()
+    kernels._candidate_buffers.clear()
+    torch.cuda.synchronize()
+    trash = [torch.full((1 << 22,), -1, dtype=torch.int32, device=device) for _ in range(8)]   # reuses freed blocks
+    for i in (1, 0):
+        for k in static_head:
+            static_head[k].copy_(heads[i][k])
+        for dst, src in zip(static_gt, gts[i]):
+            dst.copy_(src)
+        got = captured.replay()
+        torch.cuda.synchronize()
+        for a, b, name in zip(got, want[i], ("boxes", "scores", "labels", "counts", "matched")):
+            assert torch.equal(a, b), ("after the caches moved on", i, name)
+    del trash
+    for st in (captured.capture_stream, side):                     # give the 256 MiB scratch buffers back
+        for tag in ("match", "select", "nms"):
+            kernels._workspaces.pop((device.index, st.cuda_stream, tag), None)
+    torch.cuda.empty_cache()
 
 
 def test_detections_are_cut_to_size_on_first_access(device):
@@ -626,6 +656,23 @@ def test_detections_are_cut_to_size_on_first_access(device):
         assert torch.equal(d["boxes"].cpu(), r["boxes"])
     scaled[0]["boxes"] = scaled[0]["boxes"] + 1.0            # item assignment works on the materialised dictionary
     assert torch.equal(scaled[0]["boxes"].cpu(), ref[0]["boxes"] + 1.0)
+    # the rest of the mapping protocol on dictionaries nobody has looked into yet
+    fresh = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    assert fresh[0] != {} and fresh[0]._pending is None
+    more = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    assert more[0].setdefault("scores", None) is not None and more[0].setdefault("extra", 5) == 5
+    merged = more[1] | {"image_id": 3}
+    assert sorted(merged) == ["boxes", "image_id", "labels", "scores"]
+    assert sorted({"image_id": 3} | model.postprocess_detections(split, [anchors] * cfg.batch, shapes)[1]) == sorted(merged)
+    third = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    del third[0]["labels"]
+    assert sorted(third[0]) == ["boxes", "scores"] and list(reversed(third[1])) == ["labels", "scores", "boxes"]
+    third[1].clear()
+    assert len(third[1]) == 0 and "boxes" not in third[1]
+    last = model.postprocess_detections(split, [anchors] * cfg.batch, shapes)
+    assert last[0].popitem()[0] == "labels"
+    last[1] |= {"k": 1}
+    assert len(last[1]) == 4
 
 
 def test_fused_classification_loss_forward_and_backward(device):
@@ -828,3 +875,56 @@ def test_predict_tail_golden_fixture(device):
             assert np.array_equal(os_[i, :k].cpu().numpy(), g[f"scores{i}_{rule}"])
             assert np.array_equal(ol[i, :k].cpu().numpy(), g[f"labels{i}_{rule}"])
             assert np.array_equal(b[i, :int(counts[i])].cpu().numpy(), g[f"scaled{i}"])
+
+
+def test_reference_checkpoint_through_the_model_on_gpu(device, tmp_path):
+    """The reference's prediction set-up (object_detection/predict.py:44-61) on the GPU: build the model with its
+    keywords, ``torch.load`` the ``{'weights', 'height', 'width'}`` file ``train.py:118-122`` wrote (here with the loader
+    that executes nothing), ``model.load_state_dict(params['weights'])`` -- strict, as the reference calls it --
+    ``model.to(device)``, ``model.eval()``, ``model(images)``, then the loop's tail.  The detections equal, bit for bit,
+    those of the model the file was written from; the head entries carry torchvision's names."""
+    from object_detection_amd import checkpoint
+    from object_detection_amd.predict import rescale_nms
+    kw = dict(backbone="pyramid_stub", layers=[0, 1], out_channels=32, min_size=160, max_size=160, nms_thresh=0.3,
+              score_thresh=0.005, detections_per_img=80)
+    torch.manual_seed(21)
+    trained = get_model(4, **kw).to(device).eval()
+    images = [torch.rand(3, 160, 160, device=device), torch.rand(3, 120, 150, device=device),
+              torch.rand(3, 97, 131, device=device)]
+    pil_sizes = [(int(i.shape[-1]), int(i.shape[-2])) for i in images]           # PIL's img.size is (w, h)
+    with torch.no_grad():
+        want = [{k: v.clone() for k, v in d.items()} for d in trained(images)]
+        want_tail = [{k: v.clone() for k, v in d.items()}
+                     for d in rescale_nms([dict(d) for d in trained(images)], pil_sizes, (160, 160))]
+    assert sum(d["boxes"].shape[0] for d in want) > 0
+    path = str(tmp_path / "model_final.pth")
+    checkpoint.save_checkpoint(trained, path, 160, 160)
+
+    params = checkpoint.load_checkpoint(path)                                      # predict.py:46
+    assert set(params) == {"weights", "height", "width"}
+    names = set(params["weights"])
+    for name in ("head.classification_head.conv.0.0.weight", "head.classification_head.cls_logits.weight",
+                 "head.classification_head.cls_logits.bias", "head.regression_head.conv.3.0.weight",
+                 "head.regression_head.bbox_reg.weight", "head.regression_head.bbox_reg.bias"):
+        assert name in names, name
+    torch.manual_seed(99)                                                          # other initial weights
+    model = get_model(4, **kw)                                                     # predict.py:44-45
+    report = model.load_state_dict(params["weights"])                              # predict.py:49 (strict)
+    assert not report.missing_keys and not report.unexpected_keys
+    model.to(device)                                                               # predict.py:54
+    model.eval()
+    width, height = params["width"], params["height"]                              # predict.py:51-52
+    with torch.no_grad():
+        got = model(images)                                                        # predict.py:61
+        for d, w in zip(got, want):
+            for k in ("boxes", "scores", "labels"):
+                assert torch.equal(d[k], w[k]), k
+        tail = rescale_nms(model(images), pil_sizes, (width, height))              # predict.py:63-76
+    for d, w in zip(tail, want_tail):
+        assert d["boxes"].dtype is torch.int32
+        for k in ("boxes", "scores", "labels"):
+            assert torch.equal(d[k], w[k]), k
+    # a checkpoint of another class count is refused by the strict load, as torch does for the reference
+    other = get_model(7, **kw)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        other.load_state_dict(params["weights"])

@@ -45,7 +45,8 @@ def _run_both(device, batch, num_seg, seg_stride, classes, max_keep, thr, mode, 
     assert 0 < nbytes <= _C.OD_NMS_NOALLOC_SCRATCH_BYTES
     ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
     if not sorted_segments:
-        scores = scores[:, torch.randperm(scores.shape[1])].contiguous()
+        perm = torch.randperm(scores.shape[1], generator=torch.Generator().manual_seed(1000 + seed))
+        scores = scores[:, perm.to(device)].contiguous()
     rc = lib.od_batched_nms(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, sorted_segments, batch, thr, mode,
                             max_keep,
                             *[p(t) for t in want], p(ws), nbytes, stream)
@@ -74,3 +75,58 @@ def test_noalloc_nms_matches_workspace_nms_twice(device):
     null = ctypes.c_void_p(0)
     assert lib.od_batched_nms_noalloc(null, null, null, null, 8, 8192, 1, 64, 0.5, 0, 10, null, null, null, null, null,
                                       null) == -2
+
+
+def test_noalloc_nms_optional_outputs_and_graph_replay(device):
+    """keep_idx and out_labels are optional (NULL), and after one warm-up call on the device (which resolves the
+    address of the scratch array -- not a capturable operation) the entry point can be recorded into a HIP graph:
+    the replay, on new input values, gives what od_batched_nms gives."""
+    lib = _C.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    null = ctypes.c_void_p(0)
+    batch, num_seg, seg_stride, max_keep = 5, 4, 256, 1200          # unsorted and > 1024 kept: the scratch is in use
+    boxes, scores, labels, counts = _inputs(batch, num_seg, seg_stride, 3, 7, device)
+    perm = torch.randperm(scores.shape[1], generator=torch.Generator().manual_seed(7)).to(device)
+    scores = scores[:, perm].contiguous()
+    nbytes = lib.od_batched_nms_workspace_bytes(batch, num_seg, seg_stride)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def reference(bx, sc):
+        want = _outputs(batch, max_keep, device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        assert lib.od_batched_nms(p(bx), p(sc), p(labels), p(counts), num_seg, seg_stride, 0, batch, 0.5, _C.NMS_VANILLA,
+                                  max_keep, *[p(t) for t in want], p(ws), nbytes, stream) == 0
+        torch.cuda.synchronize(device)
+        return want
+
+    want = reference(boxes, scores)
+    got = _outputs(batch, max_keep, device)
+    stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    assert lib.od_batched_nms_noalloc(p(boxes), p(scores), p(labels), p(counts), num_seg, seg_stride, 0, batch, 0.5,
+                                      _C.NMS_VANILLA, max_keep, null, p(got[1]), p(got[2]), null, p(got[4]), stream) == 0
+    torch.cuda.synchronize(device)
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[4], want[4])
+    assert bool((got[0] == -7).all()) and bool((got[3] == -7).all())          # the optional outputs were left alone
+
+    # recorded: the call above was the warm-up
+    static_boxes, static_scores = boxes.clone(), scores.clone()
+    out = _outputs(batch, max_keep, device)
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        rc = lib.od_batched_nms_noalloc(p(static_boxes), p(static_scores), p(labels), p(counts), num_seg, seg_stride, 0,
+                                        batch, 0.5, _C.NMS_VANILLA, max_keep, *[p(t) for t in out],
+                                        ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    assert rc == 0
+    for seed in (8, 9):
+        nb, ns, _, _ = _inputs(batch, num_seg, seg_stride, 3, seed, device)
+        ns = ns[:, perm].contiguous()
+        static_boxes.copy_(nb)
+        static_scores.copy_(ns)
+        graph.replay()
+        torch.cuda.synchronize(device)
+        want = reference(nb, ns)
+        for name, a, b in zip(("keep_idx", "boxes", "scores", "labels", "count"), out, want):
+            assert torch.equal(a, b), f"replay, seed {seed}: {name} differs"
+        assert int(want[4].max()) > 0
