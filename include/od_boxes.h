@@ -73,6 +73,9 @@ int od_anchor_generate(const int32_t* grid_h, const int32_t* grid_w, const int32
  *   m_total             : gt_offsets[batch] as known to the host (sizes the workspace)
  *   matched             : int64 [batch, n]: matched GT index, -1 below `low`, -2 between thresholds;
  *                         an image with zero GT boxes gets all -1 (compute_loss's empty-target guard)
+ *   workspace           : od_match_retinanet_workspace_bytes(m_total, batch, n) bytes, 256-byte aligned; scratch
+ *                         without meaning between calls (nothing in it has to be initialised).  Calls that share a
+ *                         workspace must not overlap in time.
  */
 size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch, int64_t n);
 int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n, const float* gt_boxes,

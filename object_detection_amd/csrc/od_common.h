@@ -128,6 +128,17 @@ __device__ __forceinline__ uint32_t wave_sum_all(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// inclusive prefix sum over the lanes of a wave (lane i: v[0] + ... + v[i]); the same DPP steps as wave_sum_all
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+    v += dpp_u32<0x111>(v);
+    v += dpp_u32<0x112>(v);
+    v += dpp_u32<0x114, 0xf, 0xe>(v);
+    v += dpp_u32<0x118, 0xf, 0xc>(v);
+    v += dpp_u32<0x142, 0xa>(v);
+    v += dpp_u32<0x143, 0xc>(v);
+    return v;
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 // number of set bits of `mask` strictly below this lane

@@ -31,6 +31,8 @@
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
+#include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 namespace {
@@ -81,6 +83,9 @@ struct MatchWs {                 // workspace carve-up (all device pointers)
     uint4* heavy_entries;        // [heavy_cap]        x = wave tile, y = GT (as above), z = value key; image b owns the
                                  //                    slots [entry_base(b), entry_base(b) + entry_cap(b))
     long long list_stride;       // batch * wtiles
+    uint2* coop_entries;         // [batch, coop_tiles, CCAP]  one-launch path: entries of the cooperative tiles (x = GT, y = value key)
+    uint2* tile_head;            // [batch * wtiles, 8]        one-launch path: a 64-byte line per tile: (entry count, -), then its first 7 entries
+    uint2* tile_extra;           // [batch * wtiles, FEXTRA]   its further entries (both live in the memory of wave_list)
 };
 
 constexpr uint32_t kZeroKey = 0x80000000u;           // ordered_key(+0.0f), the initial per-GT maximum
@@ -786,6 +791,534 @@ __global__ __launch_bounds__(RT) void match_restore_kernel(
     }
 }
 
+// ================================================================================================================
+// One-launch matching for ordinary target counts (on average at most FUSED_AVG_GT boxes per image, at most
+// FUSED_MAX_GT in the batch).
+//
+// The four-launch chain above (init, assign, cooperative, restore) spends a third of its time in launch gaps and in
+// the tail of the cooperative kernel, which cannot start before the assign kernel has classified the last tile.
+// Here the tiles that are known to be GT-heavy before any box is read -- the coarse pyramid levels at the end of the
+// anchor list -- are given to cooperative workgroups of the SAME launch (dispatched first), every other tile is a
+// light tile whatever it meets, and nothing is queued.  No global atomics and nothing to initialise: a tile only
+// leaves its entries (GT, tile maximum); the row maxima are formed in LDS by the restore kernel.
+//
+//   match_fused_kernel        grid (image, y): y < coop_tiles -> workgroup = one cooperative tile (the last tiles
+//                             of the list), else 4 light tiles, one per wave (coarse end of the list first).
+//   match_restore_lds_kernel  grid (G, image): workgroup j of an image owns the GT rows g with g % G == j.  It reads ALL
+//                             entries of the image (about 11 000 at 786 240 anchors x 100 GT: 200 KB of entry lines out
+//                             of the L2) and keeps the maxima of its rows in LDS, reads them again (now cached),
+//                             lists the entries of its rows that equal the row's maximum and restores those row
+//                             segments (restore_row_segments, as the chain does).
+// Whole-chip time is what a step made of overlapping streams pays for: the maxima through global atomics in the fused
+// kernel (the chain's way) made that kernel 6 us longer on every CU, and the step slower, although the restore
+// kernel then was 8 us shorter -- it is a narrow kernel (G workgroups per image) that other streams' kernels run beside.
+// Rows, not tiles, are dealt to the workgroups: a workgroup that forms the maxima of all rows makes an LDS
+// look-up and an atomic for every entry of the image (11 000 x 2 LDS operations with scattered addresses: 4 us of its
+// one CU); with every G-th row it makes an eighth of them, and every entry is skipped or taken by a register test.
+// The entries of a light tile are tile-major: one 64-byte line holds the tile's entry count and its first 7 entries
+// (a tile of the fine levels meets 1.5 GT on average), read as a flat array of 16-byte words, consecutive lanes
+// consecutive words; the few tiles with more entries continue in a second array.
+// A tile with more entries than its slots hold (FCAP for a light tile, CCAP for a cooperative one) is marked -3:
+// the restore kernel recomputes that tile against the image's whole GT list, once for the maxima and once for the
+// restore.  Results are those of the chain (and of the checker) bit for bit: same tiles, same IoU code.
+constexpr int CCAP = 256;            // entry slots of a cooperative tile
+constexpr int FUSED_AVG_GT = 256;    // path used when m_total <= FUSED_AVG_GT * batch ...
+constexpr int FUSED_MAX_GT = 16384;  // ... and m_total <= this (the row maxima of an image live in LDS: 4 bytes per GT)
+constexpr int TILE_OVERFLOW = -3;
+constexpr int FHEAD = 7;             // entries of a light tile that share the 64-byte line of its entry count
+constexpr int FEXTRA = LCAP - FHEAD - 1;   // further entry slots of a light tile; capacity FHEAD + FEXTRA
+constexpr int FCAP = FHEAD + FEXTRA;
+
+__global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void match_fused_kernel(
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int coop_tiles,
+    TileLayout layout, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
+    float high, float low, long long* __restrict__ matched) {
+    constexpr int NW = MT / 64;
+    __shared__ float s_best[NW][WTILE];
+    __shared__ int s_bidx[NW][WTILE];
+    __shared__ uint2 s_ent[NW][ECAP];
+    __shared__ int s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x;
+    const int m0 = gt_offsets[b];
+    const int M = gt_offsets[b + 1] - m0;
+    long long* out = matched + (long long)b * n;
+    const float4* A = anchors + (long long)b * anchor_batch_stride;
+
+    if ((int)blockIdx.y < coop_tiles) {
+        // ---- cooperative tile: the four waves share 256 anchors and split the GT list ------------------------
+        const int ct = (int)blockIdx.y;
+        const int wt = wtiles - 1 - ct;
+        const long long wslot = (long long)b * wtiles + wt;
+        long long first[R];
+        tile_runs(layout, wt, first);
+        if (M <= 0) {
+            for (int e = threadIdx.x; e < WTILE; e += MT) {
+                long long run = first[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) run = ((e >> 6) == r) ? first[r] : run;
+                const long long idx = run + (e & 63);
+                if (idx < n) out[idx] = -1;
+            }
+            if (want_restore && threadIdx.x == 0) ws.tile_head[wslot * 8] = make_uint2(0u, 0u);
+            return;
+        }
+        if (threadIdx.x == 0) s_total = 0;
+        const bool by_chunk = M > 64 * NW * 2;      // long lists: every wave culls and scores every NW-th chunk of 64
+        const int g_first = by_chunk ? 64 * wave : 0;
+        const GtChunk head = first_gt_chunk(gt, m0, nullptr, g_first, M);
+        WaveTile t;
+        load_wave_tile(t, A, first, n);
+        __syncthreads();                            // s_total = 0 is visible
+        float best[R];
+        int bidx[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; }
+        int staged = 0;                             // wave-uniform: entries waiting in s_ent[wave]
+        uint2* region = ws.coop_entries + ((long long)b * coop_tiles + ct) * CCAP;
+        auto flush_entries = [&]() {
+            if (staged == 0) return;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // lane 0 wrote the entries, all lanes read them
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            int at = 0;
+            if (lane == 0) at = atomicAdd(&s_total, staged);
+            at = __builtin_amdgcn_readfirstlane(at);
+            if (at + staged <= CCAP)
+                for (int i = lane; i < staged; i += 64) region[at + i] = s_ent[wave][i];
+            staged = 0;
+        };
+        for_each_overlapping_gt(t, gt, m0, nullptr, g_first, M, by_chunk ? 0 : wave, by_chunk ? 1 : NW,
+            [&](int g, int, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+                const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
+                if (want_restore && k > kZeroKey) {
+                    if (lane == 0) s_ent[wave][staged] = make_uint2((uint32_t)(m0 + g), k);
+                    if (++staged == ECAP) flush_entries();
+                }
+            },
+            [&](int, uint32_t) {}, by_chunk ? NW : 1, head);
+        flush_entries();
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s_best[wave][r * 64 + lane] = best[r]; s_bidx[wave][r * 64 + lane] = bidx[r]; }
+        __syncthreads();
+        for (int e = threadIdx.x; e < WTILE; e += MT) {
+            float bb = s_best[0][e];
+            int bi = s_bidx[0][e];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) {
+                const float ob = s_best[w][e];
+                const int oi = s_bidx[w][e];
+                if (ob > bb || (ob == bb && oi < bi)) { bb = ob; bi = oi; }
+            }
+            long long run = first[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r) run = ((e >> 6) == r) ? first[r] : run;
+            const long long idx = run + (e & 63);
+            if (idx < n) {
+                out[idx] = (bb < low) ? -1 : ((bb < high) ? -2 : (long long)bi);
+                if (want_restore) put_argmax(ws, (long long)b * n + idx, bi);
+            }
+        }
+        if (want_restore && threadIdx.x == 0)
+            ws.tile_head[wslot * 8] = make_uint2((uint32_t)(s_total <= CCAP ? s_total : TILE_OVERFLOW), 0u);
+        return;
+    }
+
+    // ---- light tiles: one wave each, whatever the tile meets ----------------------------------------------------
+    const int light_tiles = wtiles - coop_tiles;
+    const int wt = light_tiles - 1 - (int)(((int)blockIdx.y - coop_tiles) * NW + wave);
+    if (wt < 0) return;
+    long long first[R];
+    tile_runs(layout, wt, first);
+    const long long wslot = (long long)b * wtiles + wt;
+    if (M <= 0) {                                   // empty-target guard of compute_loss
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long idx = first[r] + lane;
+            if (idx < n) out[idx] = -1;
+        }
+        if (want_restore && lane == 0) ws.tile_head[wslot * 8] = make_uint2(0u, 0u);
+        return;
+    }
+    constexpr int RESIDENT = 128;
+    float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA;
+    if (M <= RESIDENT) {
+        if (lane < M) gA = gt[m0 + lane];
+        if (64 + lane < M) gB = gt[m0 + 64 + lane];
+    }
+    WaveTile t;
+    load_wave_tile(t, A, first, n);
+    float best[R];
+    int bidx[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { best[r] = 0.0f; bidx[r] = 0; }
+    int lcount = 0;                                  // wave-uniform
+    uint2* head = ws.tile_head + wslot * 8;
+    uint2* extra = ws.tile_extra + wslot * FEXTRA;
+    auto eval = [&](int g, int, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+        const uint32_t k = score_gt(t, g, gx1, gy1, gx2, gy2, ga, best, bidx, want_restore != 0);
+        if (want_restore && k > kZeroKey) {          // wave-uniform: this GT overlaps an anchor of the wave
+            if (lane == 0 && lcount < FCAP)
+                (lcount < FHEAD ? head + 1 + lcount : extra + (lcount - FHEAD))[0] = make_uint2((uint32_t)(m0 + g), k);
+            ++lcount;
+        }
+    };
+    if (M <= RESIDENT) {
+        const unsigned long long maskA = __ballot(lane < M && overlaps_tile(t, gA));
+        const unsigned long long maskB = __ballot(64 + lane < M && overlaps_tile(t, gB));
+        int rank = 0;
+        visit_survivors(maskA, gA, 0, rank, 0, 1, eval);
+        if (maskB) visit_survivors(maskB, gB, 64, rank, 0, 1, eval);
+    } else {
+        for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, [&](int, uint32_t) {}, 1,
+                                first_gt_chunk(gt, m0, nullptr, 0, M));
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const long long idx = first[r] + lane;
+        if (idx < n) {
+            out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
+            if (want_restore) put_argmax(ws, (long long)b * n + idx, bidx[r]);
+        }
+    }
+    if (want_restore && lane == 0) head[0] = make_uint2((uint32_t)(lcount <= FCAP ? lcount : TILE_OVERFLOW), 0u);
+}
+
+// Low-quality restore of the one-launch path.  See the section comment above.
+constexpr int RL_T = 1024;           // threads of a workgroup
+constexpr int RL_W = RL_T / 64;
+constexpr int RL_WPT = 12;           // 16-byte words of the tiles' lines a thread requests together
+constexpr int HIT_CAP = 1024;        // hits a workgroup lists; beyond that it re-examines every tile for its rows
+constexpr int XT_CAP = 2048;         // light tiles with further entries that a workgroup lists (beyond: read one by one)
+static_assert(FEXTRA % 8 == 0 && FEXTRA < 64, "eight lanes share a tile's further entries; their number is packed into 6 bits");
+constexpr int OVER_CAP = 256;        // overflowed tiles of an image that are listed; beyond that every tile's count is scanned
+constexpr int CAND_CAP = 6144;       // entries of its rows that a workgroup lists (about 1400 at 786 240 anchors x 100 GT); beyond: as above
+
+// One tile against the rows g of its image with g % G == j.  With `matched` null: the tile's maximum of every such row is
+// merged into the LDS maxima (a tile whose entry slots overflowed).  Otherwise: every anchor that attains such a row's
+// (positive) maximum is restored.
+__device__ __forceinline__ void tile_rows_from_lds(const float4* __restrict__ A, long long n, const TileLayout& layout,
+                                                   int wt, const float4* __restrict__ gt, int m0, int M, int G, int j,
+                                                   uint32_t* s_max, const MatchWs& ws, long long image0,
+                                                   long long* __restrict__ matched) {
+    const int lane = threadIdx.x & 63;
+    long long first[R];
+    tile_runs(layout, wt, first);
+    WaveTile t;
+    load_wave_tile(t, A, first, n);
+    bool restore[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) restore[r] = false;
+    for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1,
+        [&](int g, int, int, float gx1, float gy1, float gx2, float gy2, float ga) {
+            if (g % G != j) return;
+            float v[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                v[r] = iou_pair_uniform(gx1, gy1, gx2, gy2, ga, t.ax1[r], t.ay1[r], t.ax2[r], t.ay2[r], t.aarea[r]);
+            if (matched == nullptr) {
+                float m = v[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) m = fmaxf(m, v[r]);
+                const uint32_t k = wave_umax_all(ordered_key(m));
+                if (k > kZeroKey && lane == 0) atomicMax(&s_max[g], k);
+            } else {
+                const uint32_t key = s_max[g];
+                if (!(key > kZeroKey)) return;
+#pragma unroll
+                for (int r = 0; r < R; ++r) restore[r] = restore[r] || (ordered_key(v[r]) == key);
+            }
+        },
+        [&](int, uint32_t) {}, 1, first_gt_chunk(gt, m0, nullptr, 0, M));
+    if (matched != nullptr) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const long long idx = first[r] + lane;
+            if (idx < n && restore[r]) matched[image0 + idx] = (long long)get_argmax(ws, image0 + idx);
+        }
+    }
+}
+
+__global__ __launch_bounds__(RL_T) void match_restore_lds_kernel(
+    const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int coop_tiles,
+    TileLayout layout, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
+    long long* __restrict__ matched) {
+    extern __shared__ uint32_t s_max[];                  // [M] row maxima (ordered keys; 0 = nothing overlaps); only this workgroup's rows are kept
+    __shared__ int s_hn, s_on, s_xn, s_cn;
+    __shared__ int s_hs[HIT_CAP], s_hg[HIT_CAP];
+    __shared__ uint32_t s_hk[HIT_CAP];
+    __shared__ int s_over[OVER_CAP];
+    __shared__ int s_xt[XT_CAP];                         // light tiles with more entries than their line holds: tile << 6 | further entries
+    __shared__ int s_cw[CAND_CAP];                       // entries of this workgroup's rows: tile, GT, value key
+    __shared__ uint32_t s_cg[CAND_CAP], s_ck[CAND_CAP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, j = blockIdx.x, G = gridDim.x;
+    const int m0 = gt_offsets[b];
+    const int M = gt_offsets[b + 1] - m0;
+    if (M <= 0) return;
+    const float4* A = anchors + (long long)b * anchor_batch_stride;
+    const long long image0 = (long long)b * n;
+    const long long slot0 = (long long)b * wtiles;
+    const int light_tiles = wtiles - coop_tiles;
+    // is GT `g` (index into the batch's list, as the entries hold it) one of this workgroup's rows?  G is a power of two
+    // in practice; the test is one subtraction and one AND then
+    const uint32_t gmask = (uint32_t)G - 1u;
+    const bool pow2 = (G & (G - 1)) == 0;
+    auto mine = [&](uint32_t g) {
+        const uint32_t l = g - (uint32_t)m0;
+        return pow2 ? (l & gmask) == (uint32_t)j : (l % (uint32_t)G) == (uint32_t)j;
+    };
+#ifdef OD_RL_STAMPS
+    unsigned long long rst[8];
+#define RLSTAMP(i) rst[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define RLSTAMP(i) do { } while (0)
+#endif
+    RLSTAMP(0);
+    for (int g = tid; g < M; g += RL_T) s_max[g] = 0u;
+    if (tid == 0) { s_hn = 0; s_on = 0; s_xn = 0; s_cn = 0; }
+    __syncthreads();
+    // An entry first looks (a plain read) whether it can raise its row's maximum at all: the maxima only grow, so a
+    // stale look costs an atomic that changes nothing, never a missed one.
+    auto raise_max = [&](uint32_t g, uint32_t key) {
+        const int l = (int)g - m0;
+        if (key > s_max[l]) atomicMax(&s_max[l], key);
+    };
+    auto push_hit = [&](int wt, uint32_t g, uint32_t key) {
+        const int q = atomicAdd(&s_hn, 1);
+        if (q < HIT_CAP) { s_hs[q] = (int)(slot0 + wt); s_hg[q] = (int)g; s_hk[q] = key; }
+    };
+    const int part = lane & 3;                           // which quarter of a tile's line this lane reads
+    const uint4* heads = reinterpret_cast<const uint4*>(ws.tile_head + slot0 * 8);
+    const int words = light_tiles * 4;
+    // The lines of the light tiles (count + first 7 entries, 64 bytes) are read as one flat array of 16-byte words,
+    // consecutive lanes consecutive words (one tile per lane would make a wave request touch 64 cache lines instead of
+    // 8).  A lane holds two entry slots of a tile; the tile's count sits in the first lane of its quad and is fetched
+    // with a quad broadcast.  A slot beyond the count holds whatever the memory held: it is not looked at.
+    // What bounds the kernel is the number of dependent memory round trips (1-2.5 us each for this one workgroup per
+    // CU, cached or not), so requests that do not depend on each other are issued together -- (entry lines, counts
+    // of the cooperative tiles), then (entries of the cooperative tiles, further entries of the listed tiles) -- and
+    // nothing is read twice: every entry of one of this workgroup's rows raises the row's maximum and goes to a list in
+    // LDS (about 1400 of the image's 11 000), and once the maxima are final the list is compared with them.
+    // N possible entries per lane at once (called by whole waves): one reservation in the list per wave and call
+    auto take = [&](auto n_tag, const bool* valid, const int* wt, const uint32_t* g, const uint32_t* key) {
+        constexpr int N = decltype(n_tag)::value;
+        int mine_n = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) mine_n += valid[i] ? 1 : 0;
+        const int incl = (int)wave_scan_incl((uint32_t)mine_n);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) return;
+        int base = 0;
+        if (lane == 63) base = atomicAdd(&s_cn, total);
+        int q = __builtin_amdgcn_readlane(base, 63) + incl - mine_n;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (valid[i]) {
+                raise_max(g[i], key[i]);
+                if (q < CAND_CAP) { s_cw[q] = wt[i]; s_cg[q] = g[i]; s_ck[q] = key[i]; }
+                ++q;
+            }
+        }
+    };
+    uint4 word[RL_WPT];
+    auto load_words = [&](int q0) {
+#pragma unroll
+        for (int u = 0; u < RL_WPT; ++u) {
+            const int q = q0 + u * RL_T + tid;
+            word[u] = q < words ? heads[q] : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto process_words = [&](int q0) {
+        bool valid[2 * RL_WPT];
+        int wts[2 * RL_WPT];
+        uint32_t gs[2 * RL_WPT], keys[2 * RL_WPT];
+#pragma unroll
+        for (int u = 0; u < RL_WPT; ++u) {
+            const int wt = (q0 + u * RL_T + tid) >> 2;
+            const int cnt = __builtin_amdgcn_update_dpp(0, (int)word[u].x, 0x00, 0xf, 0xf, false);   // quad_perm [0,0,0,0]
+            valid[2 * u] = part > 0 && cnt > 2 * part - 1 && mine(word[u].x);
+            valid[2 * u + 1] = cnt > 2 * part && mine(word[u].z);
+            wts[2 * u] = wts[2 * u + 1] = wt;
+            gs[2 * u] = word[u].x; keys[2 * u] = word[u].y;
+            gs[2 * u + 1] = word[u].z; keys[2 * u + 1] = word[u].w;
+            if (part == 0 && cnt == TILE_OVERFLOW) {
+                const int q = atomicAdd(&s_on, 1);
+                if (q < OVER_CAP) s_over[q] = wt;
+            }
+            if (part == 0 && cnt > FHEAD) {              // the few tiles that meet more GT: listed
+                const int q = atomicAdd(&s_xn, 1);
+                if (q < XT_CAP) s_xt[q] = (wt << 6) | (cnt - FHEAD);
+            }
+        }
+        take(std::integral_constant<int, 2 * RL_WPT>{}, valid, wts, gs, keys);
+    };
+    // cooperative tiles: a wave takes every RL_W-th one, four at a time: their counts are requested together, then all
+    // their entries (at most CCAP / 64 per lane and tile)
+    int ccnt[4];
+    uint2 cent[4][CCAP / 64];
+    auto load_coop_counts = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ct = c0 + k * RL_W;
+            ccnt[k] = ct < coop_tiles ? (int)ws.tile_head[(slot0 + wtiles - 1 - ct) * 8].x : 0;
+        }
+    };
+    auto load_coop_entries = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint2* region = ws.coop_entries + ((long long)b * coop_tiles + c0 + k * RL_W) * CCAP;
+#pragma unroll
+            for (int i = 0; i < CCAP / 64; ++i)
+                if (lane + 64 * i < ccnt[k]) cent[k][i] = region[lane + 64 * i];
+        }
+    };
+    auto process_coop = [&](int c0) {
+        constexpr int N = 4 * (CCAP / 64);
+        bool valid[N];
+        int wts[N];
+        uint32_t gs[N], keys[N];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wt = wtiles - 1 - (c0 + k * RL_W);
+            if (ccnt[k] == TILE_OVERFLOW && lane == 0) {
+                const int q = atomicAdd(&s_on, 1);
+                if (q < OVER_CAP) s_over[q] = wt;
+            }
+#pragma unroll
+            for (int i = 0; i < CCAP / 64; ++i) {
+                const int e = k * (CCAP / 64) + i;
+                valid[e] = lane + 64 * i < ccnt[k] && mine(cent[k][i].x);
+                wts[e] = wt; gs[e] = cent[k][i].x; keys[e] = cent[k][i].y;
+            }
+        }
+        take(std::integral_constant<int, N>{}, valid, wts, gs, keys);
+    };
+    // further entries of the listed tiles: eight lanes per tile, every lane requests all its entries (at most
+    // FEXTRA / 8) at once
+    constexpr int XL = 8, XPL = FEXTRA / XL;
+    const int xpart = lane & (XL - 1);
+    int x_wt = 0, x_ne = 0;
+    uint2 xent[XPL];
+    auto load_further = [&](int it, int listed_x) {
+        x_ne = 0;
+        if (it < listed_x) {
+            const int item = s_xt[it];
+            x_wt = item >> 6;
+            x_ne = item & 63;
+            const uint2* extra = ws.tile_extra + (slot0 + x_wt) * FEXTRA;
+#pragma unroll
+            for (int i = 0; i < XPL; ++i)
+                if (xpart + XL * i < x_ne) xent[i] = extra[xpart + XL * i];
+        }
+    };
+    auto process_further = [&]() {
+        bool valid[XPL];
+        int wts[XPL];
+        uint32_t gs[XPL], keys[XPL];
+#pragma unroll
+        for (int i = 0; i < XPL; ++i) {
+            valid[i] = xpart + XL * i < x_ne && mine(xent[i].x);
+            wts[i] = x_wt; gs[i] = xent[i].x; keys[i] = xent[i].y;
+        }
+        take(std::integral_constant<int, XPL>{}, valid, wts, gs, keys);
+    };
+
+    // ---- row maxima and the list of this workgroup's entries --------------------------------------------------------
+    load_words(0);
+    load_coop_counts(wave);
+    process_words(0);
+    for (int q0 = RL_T * RL_WPT; q0 < words; q0 += RL_T * RL_WPT) {
+        load_words(q0);
+        process_words(q0);
+    }
+    RLSTAMP(1);
+    __syncthreads();                                     // the lists of tiles with further entries / overflowed tiles are complete
+    const int listed_x = s_xn < XT_CAP ? s_xn : XT_CAP;
+    load_coop_entries(wave);
+    load_further(tid / XL, listed_x);
+    process_coop(wave);
+    process_further();
+    for (int c0 = wave + 4 * RL_W; c0 < coop_tiles; c0 += 4 * RL_W) {
+        load_coop_counts(c0);
+        load_coop_entries(c0);
+        process_coop(c0);
+    }
+    for (int it0 = RL_T / XL; it0 < listed_x; it0 += RL_T / XL) {      // (whole waves go round: `take` uses ballots)
+        load_further(it0 + tid / XL, listed_x);
+        process_further();
+    }
+    bool rescan = s_xn > XT_CAP;                         // block-uniform: a list was too short; every tile is re-examined below
+    {   // tiles whose entries did not fit: their maxima (of this workgroup's rows) are recomputed
+        const int over_total = s_on;
+        const int over_listed = over_total < OVER_CAP ? over_total : OVER_CAP;
+        for (int q = wave; q < over_listed; q += RL_W)
+            tile_rows_from_lds(A, n, layout, __builtin_amdgcn_readfirstlane(s_over[q]), gt, m0, M, G, j, s_max, ws, image0, nullptr);
+        if (over_total > OVER_CAP || rescan)
+            for (int wt = wave; wt < wtiles; wt += RL_W) {
+                const int cnt = (int)ws.tile_head[(slot0 + wt) * 8].x;
+                if (cnt == TILE_OVERFLOW || (rescan && cnt > FHEAD && wt < light_tiles))
+                    tile_rows_from_lds(A, n, layout, wt, gt, m0, M, G, j, s_max, ws, image0, nullptr);
+            }
+    }
+    RLSTAMP(2);
+    __syncthreads();                                     // the maxima of this workgroup's rows are final, its list is complete
+    RLSTAMP(3);
+    {   // A GT that overlaps no anchor: every anchor ties at 0 for its row and is restored (torchvision's behaviour);
+        // the workgroup that owns such a row rewrites the whole image from the stored argmax, which covers
+        // everything else it would do.
+        int any0 = 0;
+        for (int g = j + G * tid; g < M; g += G * RL_T) any0 |= (s_max[g] == 0u) ? 1 : 0;
+        if (__syncthreads_or(any0)) {
+            for (long long idx = tid; idx < n; idx += RL_T)
+                matched[image0 + idx] = (long long)get_argmax(ws, image0 + idx);
+            return;
+        }
+    }
+    // ---- the listed entries that equal their row's maximum ---------------------------------------------------------
+    const int cands = s_cn < CAND_CAP ? s_cn : CAND_CAP;
+    rescan = rescan || s_cn > CAND_CAP;
+    for (int i = tid; i < cands; i += RL_T)
+        if (s_ck[i] == s_max[(int)s_cg[i] - m0]) push_hit(s_cw[i], s_cg[i], s_ck[i]);
+    RLSTAMP(4);
+    __syncthreads();
+    RLSTAMP(5);
+    const int hits = s_hn;
+    const int listed = hits < HIT_CAP ? hits : HIT_CAP;
+    for (int h0 = wave * RB; h0 < listed; h0 += RL_W * RB) {
+        int hs[RB], hg[RB];
+        uint32_t hk[RB];
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const bool in = h0 + q < listed;
+            const int hq = in ? h0 + q : h0;
+            hs[q] = in ? __builtin_amdgcn_readfirstlane(s_hs[hq]) : -1;
+            hg[q] = __builtin_amdgcn_readfirstlane(s_hg[hq]);
+            hk[q] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_hk[hq]);
+        }
+        restore_row_segments(anchors, anchor_batch_stride, n, wtiles, layout, gt, gt_offsets, ws, hs, hg, hk, matched);
+    }
+    RLSTAMP(6);
+#ifdef OD_RL_STAMPS
+    if (lane == 0 && b == 0 && j < 2 && (wave == 0 || wave == 15))
+        printf("restore stamps (10 ns) wg %d wave %d: lines %llu rest+barrier %llu zero-check+list(%d) %llu barrier %llu hits(%d) %llu\n",
+               j, wave, rst[1] - rst[0], rst[3] - rst[1], s_cn, rst[4] - rst[3], rst[5] - rst[4], hits, rst[6] - rst[5]);
+#endif
+    // what did not fit: with more entries or ties than a list holds every tile that has entries is re-examined for this
+    // workgroup's rows; tiles whose entries overflowed always are
+    const int over_total = s_on;
+    if (rescan || hits > HIT_CAP || over_total > OVER_CAP) {
+        for (int wt = wave; wt < wtiles; wt += RL_W) {
+            const int cnt = (int)ws.tile_head[(slot0 + wt) * 8].x;
+            if ((rescan || hits > HIT_CAP) ? cnt != 0 : cnt == TILE_OVERFLOW)
+                tile_rows_from_lds(A, n, layout, wt, gt, m0, M, G, j, s_max, ws, image0, matched);
+        }
+    } else {
+        for (int q = wave; q < over_total; q += RL_W)
+            tile_rows_from_lds(A, n, layout, __builtin_amdgcn_readfirstlane(s_over[q]), gt, m0, M, G, j, s_max, ws, image0, matched);
+    }
+}
+
 // ---- FCOS centre sampling: 64 anchors per workgroup, GT staged in LDS ---------------------------------
 // A GT can match an anchor only if the anchor's centre lies within radius * size of the GT's centre.  The four
 // waves of a workgroup share 64 consecutive anchors (a piece of a row of one pyramid level, mostly; one per lane)
@@ -957,6 +1490,21 @@ __global__ __launch_bounds__(256) void matcher_col_kernel(const float* __restric
 
 static size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// Measurement knobs, read once from the environment: OD_MATCH_LEGACY=1 keeps the four-launch chain for every input
+// (A/B timing of the two paths), OD_MATCH_RESTORE_GROUPS sets the restore kernel's workgroups per image.
+static bool legacy_chain() {
+    static const bool v = [] { const char* e = getenv("OD_MATCH_LEGACY"); return e && e[0] == '1'; }();
+    return v;
+}
+static int restore_groups() {
+    static const int v = [] {
+        const char* e = getenv("OD_MATCH_RESTORE_GROUPS");
+        const int g = e ? atoi(e) : 0;
+        return (g >= 1 && g <= 64) ? g : 8;
+    }();
+    return v;
+}
+
 static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base(batch, m_total)
     return (size_t)HCAP_PER_GT * (size_t)(m_total > 0 ? m_total : 0) + 256 * (size_t)batch;
 }
@@ -965,7 +1513,10 @@ static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base
 // tiling (+1 each), and every plain segment rounds up once.
 static size_t tiles_cap(int64_t n) { return (size_t)((n + WTILE - 1) / WTILE) * 5 / 4 + 8 * MAX_SEGMENTS; }
 
-static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[9]) {
+// Most cooperative tiles the one-launch path designates (their entry regions are part of the workspace).
+static size_t coop_cap(int64_t n) { return tiles_cap(n) / 16 + 8; }
+
+static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t off[10]) {
     const size_t wtiles = tiles_cap(n);
     const size_t tiles = (size_t)batch * wtiles;
     off[0] = 0;                                                                     // gt_max_key
@@ -976,14 +1527,15 @@ static void match_ws_layout(int64_t m_total, int32_t batch, int64_t n, size_t of
     off[5] = off[4] + align256((size_t)batch * sizeof(int));                        // 256 B reserved, then heavy_count
     off[6] = off[5] + 256 + (size_t)batch * 128;                                    // heavy_queue
     off[7] = off[6] + align256(tiles * sizeof(int4));                               // heavy_entries
-    off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));     // end
+    off[8] = off[7] + align256(heavy_capacity(m_total, batch) * sizeof(uint4));     // coop_entries
+    off[9] = off[8] + align256((size_t)batch * coop_cap(n) * CCAP * sizeof(uint2)); // end
 }
 
 extern "C" size_t od_match_retinanet_workspace_bytes(int64_t m_total, int32_t batch, int64_t n) {
     if (m_total < 0 || batch < 0 || n < 0) return 0;
-    size_t off[9];
+    size_t off[10];
     match_ws_layout(m_total, batch, n, off);
-    return off[8];
+    return off[9];
 }
 
 extern "C" int od_match_retinanet(const float* anchors, int64_t anchor_batch_stride, int64_t n,
@@ -1051,7 +1603,7 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
     if (workspace_bytes < od_match_retinanet_workspace_bytes(m_total, batch, n)) return OD_ERR_WORKSPACE;
     if (!workspace || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    size_t off[9];
+    size_t off[10];
     match_ws_layout(m_total, batch, n, off);
     if (wtiles_ll > (long long)tiles_cap(n)) return OD_ERR_WORKSPACE;         // cannot happen: see tiles_cap
     const int wtiles = (int)wtiles_ll;
@@ -1068,7 +1620,41 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
     ws.heavy_queue = (int4*)(w + off[6]);
     ws.heavy_entries = (uint4*)(w + off[7]);
     ws.list_stride = total_tiles;
+    ws.coop_entries = (uint2*)(w + off[8]);
+    ws.tile_head = ws.wave_list;                                   // the one-launch path lays the same memory out tile-major
+    ws.tile_extra = ws.wave_list + (size_t)total_tiles * 8;
     const int restore = (allow_low_quality && m_total > 0) ? 1 : 0;
+    const long long stride = (long long)anchor_batch_stride;
+    // One launch (+ the restore launch) for ordinary target counts.  Cooperative tiles = the tiles after the last
+    // grid-tiled segment (the coarse pyramid levels: they meet most GT whatever the targets are); an anchor list
+    // nobody described: its last 1/32.
+    if (m_total <= (int64_t)FUSED_AVG_GT * batch && m_total <= FUSED_MAX_GT && !legacy_chain()) {
+        int coop = 0;
+        bool any_grid = false;
+        for (int k = 0; k < layout.segments; ++k) any_grid = any_grid || layout.row_len[k] > 0;
+        if (any_grid) {
+            int k = layout.segments - 1;
+            if (layout.row_len[k] == 0) coop = wtiles - (k > 0 ? layout.tile_end[k - 1] : 0);
+        } else {
+            coop = (wtiles + 31) / 32;
+        }
+        if (m_total == 0) coop = 0;
+        if (coop > (int)coop_cap(n)) coop = (int)coop_cap(n);
+        if (coop > wtiles) coop = wtiles;
+        const long long light_blocks = ((long long)(wtiles - coop) + MT / 64 - 1) / (MT / 64);
+        if (coop + light_blocks <= 65535) {
+            OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_fused_kernel, dim3((unsigned)batch, (unsigned)(coop + light_blocks)),
+                             dim3(MT), 0, s, (const float4*)anchors, stride, (long long)n, wtiles, coop, layout,
+                             (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
+            if (restore) {
+                const size_t lds = (size_t)(m_total > 0 ? m_total : 1) * sizeof(uint32_t);
+                OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_lds_kernel, dim3((unsigned)restore_groups(), (unsigned)batch),
+                                 dim3(RL_T), lds, s, (const float4*)anchors, stride, (long long)n, wtiles, coop, layout,
+                                 (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
+            }
+            return OD_OK;
+        }
+    }
     const unsigned tile_blocks = (unsigned)((wtiles + MT / 64 - 1) / (MT / 64));
     const int image_fastest = tile_blocks <= 65535u ? 1 : 0;
     dim3 grid = image_fastest ? dim3((unsigned)batch, tile_blocks) : dim3(tile_blocks, (unsigned)batch);
@@ -1077,7 +1663,6 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
         OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_INIT, match_init_kernel, dim3((unsigned)((init_threads + 255) / 256)), dim3(256),
                          0, s, ws, (long long)m_total, (int)batch, restore);
     }
-    const long long stride = (long long)anchor_batch_stride;
     OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_assign_kernel, grid, dim3(MT), ASSIGN_LDS, s, (const float4*)anchors, stride,
                      (long long)n, wtiles, layout, image_fastest, (const float4*)gt_boxes, gt_offsets, ws, restore, high, low,
                      (long long*)matched);

@@ -50,6 +50,38 @@ def test_match_retinanet(device, m):
     assert np.array_equal(out_nolq[0].numpy(), c_oracle.match_retinanet(gts[0].numpy(), anchors.numpy(), 0.6, 0.5, False))
 
 
+def test_match_retinanet_lists_that_overflow(device):
+    """The one-launch matching path keeps its intermediate results in fixed-size lists (entries per tile, tiles with
+    further entries, entries and ties per workgroup of the restore kernel, overflowed tiles per image); inputs that
+    overflow each of them take the slower routes and give the checker's answer all the same."""
+    gen = torch.Generator().manual_seed(77)
+
+    def check(anchors, gts, what):
+        out = kernels.match_retinanet(anchors.to(device), [g.to(device) for g in gts], 0.6, 0.5, True).cpu()
+        for b, g in enumerate(gts):
+            ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.6, 0.5, True)
+            assert np.array_equal(out[b].numpy(), ref), (what, b)
+
+    # (1) every anchor is the same box: every tile ties for the only GT's maximum -- more ties (1200) than a workgroup of
+    #     the restore kernel lists, and every anchor is restored
+    same = torch.tensor([[10., 10., 50., 40.]]).repeat(300_000, 1)
+    check(same, [torch.tensor([[12., 8., 60., 44.]]), torch.tensor([[0., 0., 20., 20.], [300., 300., 310., 310.]])], "ties")
+    # (2) the same with 2.1 M anchors: more entries of one GT row (8200) than a workgroup lists
+    check(same.repeat(7, 1), [torch.tensor([[12., 8., 60., 44.]])], "entries of a row")
+    # (3) ten GT that cover the whole pyramid: 2300 tiles with 10 entries each -- more tiles with further entries than
+    #     are listed
+    ag, anchors = _anchors_cpu((512, 512), (256, 16), ((16,), (64,)), (1.0,))
+    anchors = torch.cat([anchors] * 9)                                        # 592 000 anchors
+    wide = torch.tensor([[0., 0., 512., 512.]]).repeat(10, 1) + torch.arange(10).view(10, 1) * torch.tensor([[1., 2., -1., -2.]])
+    check(anchors, [wide, wide[:3]], "tiles with further entries")
+    # (4) sixty such GT on 100 000 anchors: 390 tiles whose entry slots overflow (47 per light tile) -- more than the
+    #     restore kernel lists per image; and 300 GT on a cooperative tile (256 slots)
+    ag, small = _anchors_cpu((512, 512), (100, 8), ((16,), (128,)), (1.0,))
+    small = torch.cat([small] * 10)
+    many = torch.tensor([[0., 0., 512., 512.]]).repeat(60, 1) + torch.rand((60, 1), generator=gen) * torch.tensor([[3., 5., -4., -2.]])
+    check(small, [many, torch.cat([many] * 5)], "overflowed tiles")
+
+
 def _grids_of(grids, per_location):
     """(first, row_len, rows) of every level of square pyramid grids with `per_location` anchors per cell."""
     out, first = [], 0
