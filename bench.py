@@ -11,7 +11,9 @@ are copied to pinned host memory asynchronously and read by the host at the end 
 rate with a blocking host read after every step is reported beside it (``ms_per_step_blocking_host_read``).
 Workload = BASELINE.json configs[1]: RetinaNet, 1024x1024, P2-P7, 9 anchors/location (786,240
 anchors/image), 4 classes, topk_candidates=1000, detections_per_img=500, nms_thresh=0.3,
-score_thresh=0.5, batch 16 per GPU (weak scaling: every rank processes its own 16 images).
+score_thresh=0.5, batch 16.  N > 1: `--scaling weak` (default) gives every rank its own 16 images; `--scaling strong`
+cuts ONE global batch of 16 into 16 / N images per rank (sharding.shard_bounds), the split the metric's "bs16 on 1/2/4/8
+GPU" describes; the line says which one ran, and the other one is reported beside it (`other_scaling`).
 
 Prints ONE JSON line (rank 0): images/s over all ranks, plus ``roofline`` for the dominant kernel
 (its duration measured with HIP events on the launch stream during the timed steps) and
@@ -38,19 +40,47 @@ from object_detection_amd.retinanet_model import get_model  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 NUM_CUS = 256            # compute units of one MI355X
 # HBM bytes and VALU instructions per launch from the rocprofv3 PMC counters (FETCH_SIZE, WRITE_SIZE, SQ_INSTS_VALU;
-# collected by tools/pmc_r02.sh in separate profiler runs of this same script and committed): PMC counters cannot be
-# read from inside the process.
-PMC_TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
+# collected by tools/pmc_r03.sh in separate profiler runs of this same script and committed): PMC counters cannot be
+# read from inside the process.  The file records the git blob hashes of the kernel sources it was taken from; when
+# they differ from the sources next to this script the line says `traffic_stale: true`.
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc.json")
+KERNEL_SOURCES = ("od_common.h", "od_match.hip", "od_select.hip", "od_nms.hip")
 
 
-def pmc_traffic(kernel: str):
+def source_hashes():
+    """git blob hash (sha1 of "blob <size>\\0" + content) of every kernel source the counters depend on."""
+    import hashlib
+    out = {}
+    for name in KERNEL_SOURCES:
+        try:
+            with open(os.path.join(ROOT, "object_detection_amd", "csrc", name), "rb") as f:
+                data = f.read()
+        except OSError:
+            continue
+        out[name] = hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+    return out
+
+
+def pmc_table():
     try:
-        with open(PMC_TRAFFIC_FILE) as f:
-            table = json.load(f)
+        with open(PMC_FILE) as f:
+            return json.load(f)
     except (OSError, ValueError):
-        return None
-    entry = table.get(kernel + "_kernel")
+        return {}
+
+
+def pmc_traffic(kernel: str, table=None):
+    entry = (table if table is not None else pmc_table()).get("kernels", {}).get(kernel + "_kernel")
     return None if entry is None else entry.get("hbm_bytes_per_launch")
+
+
+def minimal_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
+    """Bytes that have to cross HBM at least (per launch of a batch): like algorithmic_bytes, but a table shared by the
+    batch (the anchors: anchor_batch_stride = 0) counts once."""
+    B, N, M = cfg.batch, cfg.num_anchors, cfg.num_gt
+    if kernel == "match_assign":
+        return 16.0 * N + B * (16.0 * M + 8.0 * N)
+    return algorithmic_bytes(cfg, kernel, n_cand_per_image)
 
 
 def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
@@ -78,6 +108,10 @@ def build_inputs(cfg, rank: int, dev):
     targets = synthetic.make_targets(shifted, empty_image=cfg.batch - 1)
     head = {k: v.to(dev) for k, v in head.items()}
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
+    # the target boxes as the model's input transform hands them to compute_loss: per-image views of one buffer
+    # (transform.GeneralizedRCNNTransform.forward rescales the boxes of a batch in one buffer)
+    for t, view in zip(targets, kernels.pack_boxes([t["boxes"] for t in targets])):
+        t["boxes"] = view
     return head, targets
 
 
@@ -156,14 +190,9 @@ def launch_ranks(n: int) -> int:
     return status
 
 
-def pmc_valu(kernel: str):
+def pmc_valu(kernel: str, table=None):
     """VALU instructions per launch (SQ_INSTS_VALU summed over the waves) from the committed counter pass, or None."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_valu_match.json")) as f:
-            table = json.load(f)
-    except (OSError, ValueError):
-        return None
-    entry = table.get(kernel + "_kernel")
+    entry = (table if table is not None else pmc_table()).get("kernels", {}).get(kernel + "_kernel")
     return None if entry is None else entry.get("valu_insts_per_launch")
 
 

@@ -212,14 +212,7 @@ def retinanet_regression_loss(type: str, box_coder: BoxCoder, bbox_regression: T
     else:
         anchor_table = torch.stack([a.float() for a in anchors])
     matched = _matched_rows(matched_idxs, n)
-    offsets = [0]
-    for g in gt_boxes:
-        offsets.append(offsets[-1] + g.shape[0])
-    if offsets[-1] > 0:
-        boxes = torch.cat([g.to(torch.float32).reshape(-1, 4) for g in gt_boxes])
-    else:
-        boxes = torch.zeros((1, 4), dtype=torch.float32, device=bbox_regression.device)
-    gt_offsets = kernels._device_ints(offsets, bbox_regression.device)
+    boxes, gt_offsets, _ = kernels._pack_gt(gt_boxes, bbox_regression.device)     # in place when the transform packed them
     beta = float(cnf["beta"]) if cnf is not None and "beta" in cnf else 1.0
     eps = float(torch.finfo(bbox_regression.dtype).eps)  # as _box_loss: the epsilon of the regression's element type
     return _RetinaNetBoxLoss.apply(bbox_regression, anchor_table, matched, boxes, gt_offsets, _BOX_LOSS_TYPES[type], beta,
@@ -277,13 +270,6 @@ def fcos_head_losses(cls_logits: Tensor, bbox_regression: Tensor, bbox_ctrness: 
     else:
         anchor_table = torch.stack([a.float() for a in anchors])
     matched = _matched_rows(matched_idxs, n)
-    offsets = [0]
-    for t in targets:
-        offsets.append(offsets[-1] + t["boxes"].shape[0])
-    if offsets[-1] > 0:
-        boxes = torch.cat([t["boxes"].to(torch.float32).reshape(-1, 4) for t in targets])
-    else:
-        boxes = torch.zeros((1, 4), dtype=torch.float32, device=cls_logits.device)
-    gt_offsets = kernels._device_ints(offsets, cls_logits.device)
+    boxes, gt_offsets, _ = kernels._pack_gt([t["boxes"] for t in targets], cls_logits.device)
     reg, ctr = _FCOSBoxLoss.apply(bbox_regression, bbox_ctrness, anchor_table, matched, boxes, gt_offsets, 1e-7)
     return {"classification": cls, "bbox_regression": reg, "bbox_ctrness": ctr}

@@ -141,6 +141,19 @@ def anchor_generate(grid_sizes: Sequence[Tuple[int, int]], strides: Sequence[Tup
     return set_anchor_grids(out, firsts)
 
 
+def pack_boxes(box_list: Sequence[Tensor]) -> list:
+    """The boxes of a batch in ONE fp32 buffer [sum M, 4], handed back as per-image views in list order.  The matching and
+    loss launchers recognise such a list (consecutive views of one buffer) and read the buffer where it is; any other
+    list is concatenated at every call.  The input transform hands the target boxes over this way."""
+    if len(box_list) == 0:
+        return []
+    dev = box_list[0].device
+    sizes = [int(b.shape[0]) for b in box_list]
+    packed = torch.cat([b.reshape(-1, 4).to(torch.float32) for b in box_list]) if sum(sizes) > 0 else \
+        torch.zeros((0, 4), dtype=torch.float32, device=dev)
+    return list(packed.split(sizes))
+
+
 def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, Tensor, int]:
     offsets = [0]
     plain = True                      # every tensor already fp32 [M, 4]: concatenate as they are
@@ -149,7 +162,19 @@ def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, T
         plain = plain and g.dtype is torch.float32 and g.dim() == 2
     m_total = offsets[-1]
     if m_total > 0:
-        if plain:
+        first = gt_list[0]
+        packed = None
+        if plain and first.is_cuda:
+            # consecutive views of one buffer (pack_boxes): nothing to copy
+            p0 = first.data_ptr()
+            if all(g.data_ptr() == p0 + 16 * o and g.is_contiguous() and g.shape[-1] == 4
+                   for g, o in zip(gt_list, offsets)) and \
+                    first.untyped_storage().nbytes() - first.storage_offset() * 4 >= 16 * m_total and \
+                    all(g.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for g in gt_list[1:]):
+                packed = torch.as_strided(first, (m_total, 4), (4, 1), first.storage_offset())
+        if packed is not None:
+            gt = packed
+        elif plain:
             gt = torch.cat(gt_list)   # cat returns a fresh contiguous tensor; empty [0, 4] entries are fine
         else:
             gt = torch.cat([_f32c(g.reshape(-1, 4)) for g in gt_list if g.shape[0] > 0]).contiguous()

@@ -83,7 +83,24 @@ class GeneralizedRCNNTransform(nn.Module):
         out_h = int(math.ceil(float(max(r[0] for r in resized)) / stride) * stride)
         out_w = int(math.ceil(float(max(r[1] for r in resized)) / stride) * stride)
         batched = kernels.preprocess_images(images, resized, self.image_mean, self.image_std, (out_h, out_w))
-        if targets is not None:
+        if targets is not None and all("boxes" in t for t in targets):
+            # resize_boxes for the whole batch: the boxes of all images in one buffer (two launches instead of one per
+            # image), scaled by each image's ratios, handed back as per-image views -- which the matching and loss
+            # kernels then read in place
+            boxes = [t["boxes"] for t in targets]
+            if all(b.is_cuda and b.dim() == 2 and b.shape[-1] == 4 for b in boxes) and sum(int(b.shape[0]) for b in boxes) > 0:
+                views = kernels.pack_boxes(boxes)
+                packed = torch.as_strided(views[0], (sum(int(v.shape[0]) for v in views), 4), (4, 1), views[0].storage_offset())
+                flat = [v for old, new in zip(sizes, resized) for v in _box_ratios(old, new)]
+                ratios = kernels._device_floats(flat, packed.device).view(-1, 4)
+                counts = kernels._device_ints([int(v.shape[0]) for v in views], packed.device, torch.int64)
+                packed.mul_(torch.repeat_interleave(ratios, counts, dim=0, output_size=packed.shape[0]))
+                for t, v in zip(targets, views):
+                    t["boxes"] = v
+            else:
+                for t, old, new in zip(targets, sizes, resized):
+                    t["boxes"] = resize_boxes(t["boxes"], old, new)
+        elif targets is not None:
             for t, old, new in zip(targets, sizes, resized):
                 if "boxes" in t:
                     t["boxes"] = resize_boxes(t["boxes"], old, new)
