@@ -13,7 +13,7 @@ Workload = BASELINE.json configs[1]: RetinaNet, 1024x1024, P2-P7, 9 anchors/loca
 anchors/image), 4 classes, topk_candidates=1000, detections_per_img=500, nms_thresh=0.3,
 score_thresh=0.5, batch 16.  N > 1: `--scaling weak` (default) gives every rank its own 16 images; `--scaling strong`
 cuts ONE global batch of 16 into 16 / N images per rank (sharding.shard_bounds), the split the metric's "bs16 on 1/2/4/8
-GPU" describes; the line says which one ran, and the other one is reported beside it (`other_scaling`).
+GPU" describes; the line says which one ran.
 
 Prints ONE JSON line (rank 0): images/s over all ranks, plus ``roofline`` for the dominant kernel
 (its duration measured with HIP events on the launch stream during the timed steps) and
@@ -101,11 +101,18 @@ def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
     }.get(kernel, 0.0)
 
 
-def build_inputs(cfg, rank: int, dev):
-    """Synthetic batch, generated on the CPU from fixed seeds, then copied to the device."""
-    shifted = dataclasses.replace(cfg, cfg_id=cfg.cfg_id + 100 * rank)   # different images per rank
-    head = synthetic.make_head_outputs(shifted)
-    targets = synthetic.make_targets(shifted, empty_image=cfg.batch - 1)
+def build_inputs(cfg, rank: int, dev, images=None):
+    """Synthetic batch, generated on the CPU from fixed seeds, then copied to the device.  `images`: the (lo, hi) slice
+    of the global batch this rank takes (strong scaling: every rank generates the same global batch and keeps its
+    share); default: the whole batch, with other images on every rank."""
+    if images is None:
+        shifted = dataclasses.replace(cfg, cfg_id=cfg.cfg_id + 100 * rank)   # different images per rank
+        head = synthetic.make_head_outputs(shifted)
+        targets = synthetic.make_targets(shifted, empty_image=cfg.batch - 1)
+    else:
+        lo, hi = images
+        head = synthetic.make_head_outputs(cfg, images=range(lo, hi))
+        targets = synthetic.make_targets(cfg, empty_image=cfg.batch - 1)[lo:hi]
     head = {k: v.to(dev) for k, v in head.items()}
     targets = [{k: v.to(dev) for k, v in t.items()} for t in targets]
     # the target boxes as the model's input transform hands them to compute_loss: per-image views of one buffer
@@ -215,6 +222,9 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="timed region: replay the step's recorded HIP graph instead of launching every kernel from the "
                          "host (measured slower on this runtime; without the flag the replay rate is a secondary figure)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("OD_BENCH_SCALING", "weak"),
+                    help="N > 1: weak = every rank processes its own batch of 16 images; strong = one global batch of 16 "
+                         "images is cut into 16 / N per rank")
     ap.add_argument("--lean", action="store_true",
                     help="only warm-up, kernel probe and the timed region (for profiling: the kernel statistics of the "
                          "run are then those of the timed region); the secondary figures are reported as null")
@@ -237,8 +247,8 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(170, exit=True)      # a hang ends with the stack of every thread
         local_rank = 0
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if rehearsal:
             dist.init_process_group("gloo")
@@ -248,7 +258,21 @@ def main():
     torch.cuda.set_device(dev)
     use_graph = args.graph
 
-    cfg = synthetic.CFG2
+    global_cfg = synthetic.CFG2
+    cfg, shard = global_cfg, None
+    ranks_seen, backend = 1, None
+    if world > 1:
+        backend = dist.get_backend()
+        ones = torch.ones((1,), dtype=torch.int32, device="cpu" if rehearsal else dev)
+        dist.all_reduce(ones)                                   # every rank that joined adds one (over RCCL unless rehearsing)
+        ranks_seen = int(ones.item())
+        if args.scaling == "strong":
+            if global_cfg.batch % world:
+                print(f"bench.py: --scaling strong cuts a batch of {global_cfg.batch} images into equal shards; "
+                      f"{world} ranks do not divide it", file=sys.stderr)
+                sys.exit(2)
+            shard = sharding.shard_bounds(global_cfg.batch, rank, world)
+            cfg = dataclasses.replace(global_cfg, batch=shard[1] - shard[0])
     L = len(cfg.grids)
     model = get_model(cfg.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
                       score_thresh=cfg.score_thresh, nms_thresh=cfg.nms_thresh,
@@ -268,7 +292,7 @@ def main():
     n_rot = max(2, args.rotate + (args.rotate & 1))
     batches = []
     for r in range(n_rot):
-        head, targets_r = build_inputs(dataclasses.replace(cfg, cfg_id=cfg.cfg_id + 10 * r), rank, dev)
+        head, targets_r = build_inputs(dataclasses.replace(global_cfg, cfg_id=global_cfg.cfg_id + 10 * r), rank, dev, images=shard)
         batches.append(({k: list(v.split(sizes, dim=1)) for k, v in head.items()}, targets_r))
     split, targets = batches[0]
     shapes = [cfg.image_size] * cfg.batch
@@ -547,8 +571,27 @@ def main():
             record_graphs()
             ms_graph = timed_loop(graph_step_run, min(args.steps, 100))
 
+    # every kernel inside the overlapped step: a loop of eager steps after the timed region with every 8th launch of
+    # every kernel timed (start / stop events on the dispatch)
+    in_step = {}
+    if not args.lean:
+        _C.profile_select(_C.PROFILE_ALL)
+        _C.profile_stride(8)
+        for k in range(len(_C.KERNEL_NAMES)):
+            _C.profile_read(k)
+        timed_loop(lambda i: eager_step(i), max(64, min(args.steps, 200)))
+        for k, name in enumerate(_C.KERNEL_NAMES):
+            ms, n = _C.profile_read(k)
+            if n:
+                in_step[name] = ms / n
+        _C.profile_select(_C.PROFILE_OFF)
+        _C.profile_stride(1)
+    reference_loops = None
+    if not args.lean and world == 1:
+        torch.cuda.set_stream(default_stream)
+        reference_loops = reference_loop_figures(dev, timed_loop)
+
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -564,8 +607,28 @@ def main():
             p["algorithmic_MB"] = b / 1e6
             p["GBps"] = b / (p["ms_per_launch"] * 1e-3) / 1e9 if p["ms_per_launch"] > 0 else 0.0
         is_match = dominant.startswith("match")
-        traffic = pmc_traffic(dominant)
-        valu = pmc_valu(dominant)
+        table = pmc_table()
+        stale = table.get("source_hashes") != source_hashes()
+        traffic = pmc_traffic(dominant, table)
+        valu = pmc_valu(dominant, table)
+        # every kernel of the step: contract bytes (SURVEY formulas), minimal bytes (a table shared by the batch counts
+        # once), counter traffic, duration alone and inside the overlapped step, and the fraction of the HBM peak each
+        # pair gives
+        roofline_all = []
+        for name, pr in sorted(probe.items(), key=lambda kv: -kv[1]["ms_per_launch"]):
+            alone = pr["ms_per_launch"] * 1e-3
+            inside = in_step.get(name, 0.0) * 1e-3
+            cb, mb, tr = algorithmic_bytes(cfg, name, n_cand), minimal_bytes(cfg, name, n_cand), pmc_traffic(name, table)
+            frac = lambda b, t: (b / t / 1e9 / HBM_PEAK_GBS) if (b and t > 0) else None
+            roofline_all.append({
+                "kernel": name, "launches_per_step": pr["launches_per_step"], "cu_share": pr["cu_share"],
+                "us_alone": alone * 1e6, "us_in_step": inside * 1e6 if inside else None,
+                "contract_MB": cb / 1e6, "minimal_MB": mb / 1e6, "traffic_MB": tr / 1e6 if tr else None,
+                "frac_contract_alone": frac(cb, alone), "frac_contract_in_step": frac(cb, inside),
+                "frac_minimal_alone": frac(mb, alone), "frac_minimal_in_step": frac(mb, inside),
+                "frac_traffic_alone": frac(tr, alone), "valu_insts": pmc_valu(name, table),
+            })
+        longest = max(probe, key=lambda name: probe[name]["ms_per_launch"])
         # a wave64 fp32 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
         valu_issue_s = (valu * 4.0 / (NUM_CUS * 4 * 2.4e9)) if valu else None
         result = {
@@ -596,7 +659,10 @@ def main():
                 "match_pairs_per_s": cfg.batch * cfg.num_anchors * cfg.num_gt / (ms_match * 1e-3),
             },
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling if world > 1 else "weak",
+            "ranks_seen": ranks_seen,
+            "collective_backend": backend,
+            "images_per_rank_per_step": cfg.batch,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -606,19 +672,27 @@ def main():
                             f"step = match ({cfg.num_gt} GT/image, fg .6 / bg .5) + postprocess",
                 "batch_per_gpu": cfg.batch,
                 "global_batch": cfg.batch * world,
+                "split": ("one global batch of %d images cut into %d per rank" % (global_cfg.batch, cfg.batch)) if shard else
+                         "every rank processes its own batch",
                 "anchors_per_image": cfg.num_anchors,
                 "candidates_per_image": n_cand,
                 "logits": "synthetic 'stress' distribution N(-3, 1.5) + 0.1% saturated: 2.3% of the logits pass "
                           "score_thresh, every level overflows topk_candidates",
                 "parallelism": f"image-sharded x{world}" + (
                     (f", all-gather of the padded detections of {args.gather_every} steps at a time (" +
-                     ("gloo over host memory: rehearsal on one GPU" if rehearsal else "RCCL") + ")") if world > 1 else ""),
+                     ("gloo over host memory: rehearsal on one GPU" if rehearsal else "RCCL") +
+                     "): the collective runs once per " + str(args.gather_every) + " steps and stream, so ms_per_step "
+                     "holds an eighth of its cost, not a collective per step") if world > 1 else ""),
                 "resident_batches_in_rotation": n_rot,
                 "hip_streams_eager": args.streams,
             },
             "roofline": {
                 "kernel": dominant,
                 "dominant_by": "duration x share of the 256 CUs the grid can fill (kernels[*].cu_share)",
+                "longest_kernel_by_plain_duration": longest,
+                "traffic_stale": stale,
+                "minimal_MB_per_launch": minimal_bytes(cfg, dominant, n_cand) / 1e6,
+                "frac_minimal_bytes": (minimal_bytes(cfg, dominant, n_cand) / dur_s / 1e9 / HBM_PEAK_GBS) if dur_s > 0 else None,
                 # the matching kernels are bound by VALU issue, not by HBM: the anchors are shared by the batch and
                 # served from L2, so the bytes that cross HBM (`traffic`) are about half the algorithmic bytes
                 "bound": "valu" if is_match else "hbm",
@@ -644,6 +718,8 @@ def main():
                 "frac_alone": (abytes / alone_s / 1e9) / HBM_PEAK_GBS,
             },
             "kernels": probe,
+            "roofline_all": roofline_all,
+            "reference_loops": reference_loops,
         }
         if world == 1 and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
@@ -653,6 +729,73 @@ def main():
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+
+
+def reference_loop_figures(dev, timed_loop):
+    """What the reference's own loops see (none of this is `value`): validation and prediction run `model(images)` with
+    batch_size 1 and look at the result at once (reference train.py:84-85,104, predict.py:61-76); training runs
+    compute_loss forward + backward and reads the loss with .item() every step at batch_size 8
+    (configs/config_all.py:3, train.py:62-66).  Thresholds of configs/config_all.py:10-15: topk_candidates 1000,
+    detections_per_img 300, score_thresh .5, nms_thresh .3, fg .6 / bg .5; 1024 x 1024, the bench's pyramid and logits."""
+    from object_detection_amd.retinanet import postprocess_batched
+    out = {}
+    ref = dataclasses.replace(synthetic.CFG2, detections_per_img=300)
+    L = len(ref.grids)
+    sizes = synthetic.level_sizes(ref)
+    model = get_model(ref.num_classes, layers=list(range(L - 2)), backbone="pyramid_stub", out_channels=32,
+                      score_thresh=0.5, nms_thresh=0.3, topk_candidates=1000, detections_per_img=300,
+                      fg_iou_thresh=0.6, bg_iou_thresh=0.5, min_size=1024, max_size=1024).to(dev).eval()
+    grids = [(g, g) for g in ref.grids]
+    strides = [(ref.image_size[0] // g, ref.image_size[1] // g) for g in ref.grids]
+    anchors_flat, _ = model.anchor_generator._grid_anchors_flat(grids, strides, dev)
+    anchors_l = list(anchors_flat.split(sizes))
+    # ---- validation / prediction: one image per call, every result read at once
+    one = dataclasses.replace(ref, batch=1)
+    heads = []
+    for r in range(4):
+        h = synthetic.make_head_outputs(dataclasses.replace(one, cfg_id=one.cfg_id + 50 + r))
+        heads.append({k: [t.to(dev) for t in v.split(sizes, dim=1)] for k, v in h.items()})
+
+    def validate(i):
+        dets = model.postprocess_detections(heads[i % 4], [anchors_l], [ref.image_size])
+        return [(d["boxes"], d["scores"], d["labels"]) for d in dets]       # the first access waits for the GPU
+
+    out["validation_b1_postprocess_ms"] = timed_loop(validate, 200)
+    _C.profile_select(_C.PROFILE_ALL)
+    for k in range(len(_C.KERNEL_NAMES)):
+        _C.profile_read(k)
+    for i in range(20):
+        validate(i)
+    torch.cuda.synchronize(dev)
+    chain = {}
+    for k, name in enumerate(_C.KERNEL_NAMES):
+        ms, n = _C.profile_read(k)
+        if n:
+            chain[name] = 1e3 * ms / n
+    _C.profile_select(_C.PROFILE_OFF)
+    out["validation_b1_kernel_us"] = chain
+    out["validation_b1_kernel_chain_us"] = sum(chain.values())
+    out["validation_b1_images_per_s"] = 1e3 / out["validation_b1_postprocess_ms"]
+    # ---- training: compute_loss forward + backward + .item() at the reference's batch size
+    tb = dataclasses.replace(ref, batch=8)
+    head = {k: v.to(dev).requires_grad_(True) for k, v in synthetic.make_head_outputs(dataclasses.replace(tb, cfg_id=tb.cfg_id + 70)).items()}
+    targets = [{k: v.to(dev) for k, v in t.items()} for t in synthetic.make_targets(tb)]
+    for t, view in zip(targets, kernels.pack_boxes([t["boxes"] for t in targets])):
+        t["boxes"] = view
+    model.train()
+
+    def train_step(i):
+        for v in head.values():
+            v.grad = None
+        losses = model.compute_loss(targets, head, [anchors_flat] * tb.batch)
+        total = losses["classification"] + losses["bbox_regression"]
+        value = total.item()                                               # reference train.py:64
+        total.backward()
+        return value
+
+    out["train_b8_compute_loss_fwd_item_bwd_ms"] = timed_loop(train_step, 50)
+    model.eval()
+    return out
 
 
 def kernels_candidates_per_image(cfg, split, split_anchors, shapes, model) -> float:

@@ -35,6 +35,7 @@ using namespace od;
 
 constexpr int NT = 1024;              // threads per workgroup
 constexpr int S = 256;                // strip length
+static_assert(S == 256, "a merge of the ordering tree is one wave x 4 keys per lane; window entries are decoded with >> 8");
 constexpr int SB = S / 64;            // 64-candidate blocks per strip
 constexpr int MAXN = OD_MAX_NMS_BOXES;
 constexpr int WSEG = 8;               // pre-sorted segments that are merged lazily (more: ranked beforehand)
@@ -42,6 +43,11 @@ constexpr int KC = 1024;              // kept boxes cached in LDS (later ones ar
 constexpr int CW = SB * 2 + 1;        // u32 words per column of the bit matrix (+1 pad against bank conflicts)
 constexpr int MAX_SEG = 64;
 constexpr int NMS_MODE_MASK = 0xff;
+constexpr int RK = 896;               // candidates at the head of the order that are ranked in one go (a multiple of 64; with the
+                                      // 16 * WSEG entries behind the last samples one pass of the workgroup ranks them) ...
+constexpr int RSEG = 1024;            // ... when the (at most WSEG) sorted segments hold at most this many entries each
+static_assert(WSEG * RSEG * 4 >= (WSEG * S + (WSEG / 2) * S) * 8 + WSEG * S * 4, "the window arrays share the memory of the segment keys");
+static_assert(RK % 64 == 0 && RK + 16 * WSEG <= NT, "strips start at multiples of 64; one pass of the workgroup ranks the head");
 
 struct NmsArgs {
     const float4* boxes;
@@ -116,8 +122,17 @@ __device__ __forceinline__ int count_greater(const unsigned long long* arr, int 
 }
 
 __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
-    __shared__ uint32_t s_win[WSEG * S];                // the next S score keys of every segment (0: past the end)
-    __shared__ int s_wslot[WSEG * S];                   // their slots
+    // 32 KB used in two ways: while the head of the order is ranked in one go (see RK), the score keys of up to WSEG
+    // segments of up to RSEG entries; afterwards the windows of the lazy merge:
+    __shared__ unsigned long long s_raw[WSEG * RSEG / 2];
+    unsigned long long* const s_wk = s_raw;                          // [WSEG * S] the next S keys of every segment: score key << 32 | ~window entry (0: past the end)
+    unsigned long long* const s_mk = s_raw + WSEG * S;               // [WSEG / 2 * S] second buffer of the merge tree
+    int* const s_wslot = reinterpret_cast<int*>(s_raw + WSEG * S + (WSEG / 2) * S);   // [WSEG * S] the window entries' slots
+    uint32_t* const s_key = reinterpret_cast<uint32_t*>(s_raw);      // [WSEG * RSEG] score keys of whole segments (0: past the end)
+    __shared__ int s_order[RK];                         // slot of the r-th candidate of the image, r < RK
+    __shared__ int s_olab[RK];                          // its label
+    __shared__ __attribute__((aligned(16))) float4 s_obox[RK];       // its box
+    __shared__ int s_cut[WSEG];                         // entries at the head of every segment that may rank below RK
     __shared__ int s_wlab[WSEG * S];                    // their labels
     __shared__ __attribute__((aligned(16))) float4 s_sbox[S];   // box of the strip's r-th candidate (as given)
     __shared__ int s_sraw[S];                           // its label as given
@@ -133,7 +148,6 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     __shared__ unsigned int s_col[S * CW];
     __shared__ int s_strip[S];                          // slot of the strip's r-th candidate (score order)
     __shared__ __attribute__((aligned(16))) uint32_t s_ckey[S];   // its (class, rank) key
-    __shared__ int s_srank[WSEG * 16];                  // rank of every 16th window entry
     __shared__ int s_crank[S];                          // its position in (class, rank) order
     __shared__ int s_cpos[S];                           // inverse: rank of the candidate at class-order position c
     __shared__ int s_flag[S];                           // A: dead; later: kept, by rank
@@ -208,7 +222,34 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
             }
         }
     };
-    prefetch_windows();
+    // The head of the order in one go.  The pipeline hands over up to WSEG sorted segments of up to RSEG entries (one per
+    // pyramid level, topk_candidates each) and stops after a few hundred candidates: the first RK candidates of the
+    // image are ranked once -- all score keys in LDS, rank of an entry = its position + the entries of the other
+    // segments that precede it, found by binary searches that advance together (one LDS round trip per level); ranks
+    // grow along a segment, so an entry whose preceding sample (every 16th entry is ranked first) already has rank >=
+    // RK is skipped -- and their boxes and labels are brought into LDS.  The strips of the first RK candidates then
+    // need no memory access and no ordering step (ordering every strip of 256 from windows of the segments, which is
+    // what happens beyond RK and for longer segments, took a third of the kernel: 5-6 us per strip).
+    const bool ranked = a.lazy && nseg > 1 && a.seg_stride <= RSEG;
+    const int ranked_n = ranked ? (n_valid < RK ? n_valid : RK) : 0;
+    if (ranked) {
+        static_assert(RSEG == NT, "thread t holds entry t of every segment");
+        float sc[WSEG];                              // all requests first: one memory round trip, not one per segment
+        bool ok[WSEG];
+#pragma unroll
+        for (int l = 0; l < WSEG; ++l) {
+            ok[l] = l < nseg && tid < s_segpre[l + 1] - s_segpre[l];
+            sc[l] = ok[l] ? scores[l * a.seg_stride + tid] : 0.0f;
+        }
+#pragma unroll
+        for (int l = 0; l < WSEG; ++l) {
+            const uint32_t sk = ordered_key(sc[l]);
+            // a valid entry: at least 1 (only the two lowest NaN patterns share a key)
+            s_key[l * RSEG + tid] = ok[l] ? (sk > 1u ? sk : 1u) : 0u;
+        }
+    } else {
+        prefetch_windows();
+    }
 
     int mode = a.mode & NMS_MODE_MASK;
     if (mode == OD_NMS_AUTO_CPU) mode = (4 * n_valid > 4000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
@@ -272,6 +313,78 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
     }
     STAMP(1);
 
+    if (ranked) {
+        static_assert(RSEG == 1024, "entries are decoded with >> 10");
+        __syncthreads();                                 // the keys are in place
+        // Entry (segment l, position i, score key k) is preceded by the entries of segment o with a greater score key
+        // and, for o < l, by those with the same key (equal scores: lower slot first, and slots grow with the segment).
+        auto segment_rank = [&](int l, int i, uint32_t k) -> int {
+            int cnt[WSEG];
+            uint32_t bar[WSEG];                          // entries above bar[o] precede (k >= 1)
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) { cnt[o] = 0; bar[o] = k - (o < l ? 1u : 0u); }
+            for (int st = RSEG >> 1; st >= 1; st >>= 1) {
+                uint32_t v[WSEG];
+#pragma unroll
+                for (int o = 0; o < WSEG; ++o) v[o] = o < nseg ? s_key[o * RSEG + cnt[o] + st - 1] : 0u;
+#pragma unroll
+                for (int o = 0; o < WSEG; ++o) cnt[o] += (v[o] > bar[o]) ? st : 0;
+            }
+            int rank = i;
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) {             // the search stops at RSEG - 1: the last entry decides
+                cnt[o] += (cnt[o] == RSEG - 1 && s_key[o * RSEG + RSEG - 1] > bar[o]) ? 1 : 0;
+                rank += (o != l) ? cnt[o] : 0;
+            }
+            return rank;
+        };
+        if (tid < nseg * (RSEG / 16)) {
+            const int l = tid >> 6, i = ((tid & 63) << 4) | 15;
+            const uint32_t key = s_key[l * RSEG + i];
+            const int sr = key != 0u ? segment_rank(l, i, key) : 0x7fffffff;
+            // ranks grow along a segment: the samples below RK are a prefix, and only the entries up to the block of
+            // 16 behind the last of them can have a rank below RK
+            const int below = __popcll(__ballot(sr < RK));          // wave l holds the samples of segment l
+            if (lane == 0) {
+                const int len = s_segpre[l + 1] - s_segpre[l];
+                const int cut = 16 * (below + 1);
+                s_cut[l] = cut < len ? cut : len;
+            }
+        }
+        __syncthreads();
+        // the entries to rank, dealt to all threads: entry w of the concatenated heads of the segments
+        int cpre[WSEG + 1];
+        cpre[0] = 0;
+#pragma unroll
+        for (int o = 0; o < WSEG; ++o) cpre[o + 1] = cpre[o] + (o < nseg ? s_cut[o] : 0);
+        for (int w0 = 0; w0 < cpre[WSEG]; w0 += NT) {
+            const int w = w0 + tid;
+            const bool on = w < cpre[WSEG];
+            int l = 0;
+#pragma unroll
+            for (int o = 1; o < WSEG; ++o) l += (on && w >= cpre[o]) ? 1 : 0;
+            int base = 0;
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) base = (o == l) ? cpre[o] : base;
+            const int i = on ? w - base : 0;
+            const int rank = on ? segment_rank(l, i, s_key[l * RSEG + i]) : RK;
+            const bool in = rank < RK;
+            if (in) s_order[rank] = l * a.seg_stride + i;
+#pragma unroll
+            for (int o = 0; o < WSEG; ++o) {                        // entries consumed from every segment
+                const unsigned long long m = __ballot(in && l == o);
+                if (lane == 0 && m != 0ull) atomicAdd(&s_head[o], __popcll(m));
+            }
+        }
+        __syncthreads();
+        if (tid < ranked_n) {
+            const int slot = s_order[tid];
+            s_obox[tid] = boxes[slot];
+            s_olab[tid] = labels ? labels[slot] : 0;
+        }
+        // (the first strip reads them after its own barriers)
+    }
+
     const int max_keep = a.max_keep < n_valid ? a.max_keep : n_valid;
     ThrBand thr;
     thr.up = a.thr_up;
@@ -293,20 +406,36 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
             const int target = want + (want >> 1);
             SL = target <= 64 ? 64 : (target <= 128 ? 128 : S);      // power of two
         }
+        const bool from_order = s0 < ranked_n;               // this strip lies in the head that was ranked in one go
+        while (from_order && s0 + SL > ranked_n && ranked_n < n_valid) SL >>= 1;   // ... entirely (s0 and RK are multiples of 64)
         const int slog = SL == 64 ? 6 : (SL == 128 ? 7 : 8);
         const int ns = (n_valid - s0) < SL ? (n_valid - s0) : SL;    // candidates of this strip
         const int parts = NT / SL;
 
+        if (from_order) {
+            for (int i = tid; i < S * CW; i += NT) s_col[i] = 0u;
+            if (tid < S) {
+                s_flag[tid] = 0; s_crank[tid] = 0; s_ckey[tid] = 0xFFFFFFFFu;
+                if (tid < ns) {
+                    const int lab = s_olab[s0 + tid];
+                    s_strip[tid] = s_order[s0 + tid];
+                    s_sraw[tid] = lab;
+                    if (group) s_ckey[tid] = ((uint32_t)(lab - label_base) << 8) | (uint32_t)tid;
+                }
+            }
+            __syncthreads();
+        } else {
         // -- windows: the next S keys of every segment (requested during the previous strip) -------------------
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = tid + u * NT;
-            if (e < nseg * S) {
-                // score key of a valid entry: at least 1 (only the two lowest NaN patterns share a key)
+            if (e < WSEG * S) {
+                // score key of a valid entry: at least 1 (only the two lowest NaN patterns share a key).  Equal scores:
+                // the lower window entry first, i.e. the lower slot (slots grow with the segment and the position).
                 const uint32_t sk = ordered_key(pf_score[u]);
-                s_win[e] = pf_slot[u] >= 0 ? (sk > 1u ? sk : 1u) : 0u;
-                s_wslot[e] = pf_slot[u];
-                s_wlab[e] = pf_lab[u];
+                const bool ok = e < nseg * S && pf_slot[u] >= 0;
+                s_wk[e] = ok ? (((unsigned long long)(sk > 1u ? sk : 1u) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)e)) : 0ull;
+                if (e < nseg * S) { s_wslot[e] = pf_slot[u]; s_wlab[e] = pf_lab[u]; }
             }
         }
         for (int i = tid; i < S * CW; i += NT) s_col[i] = 0u;
@@ -315,61 +444,75 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
 #ifdef OD_STAMPS_FINE
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
-        // -- rank inside the union of the windows; rank < ns makes the strip ----------------------------------------
-        // Ranks grow along a window, so most entries are ruled out by a sample: two waves rank every 16th entry of
-        // every window; an entry whose preceding sample already has rank >= ns is not in the strip and skips the
-        // search.  About ns + 16 * nseg entries remain, in whole waves at the head of every window.
-        // Entry (window l, position i, score key k) is preceded by the entries of window o with a greater score key
-        // and, for o < l, by those with the same key (equal scores: lower slot first, and slots grow with the
-        // segment).  The binary searches in all windows advance together: one LDS round trip per level.
-        auto window_rank = [&](int l, int i, uint32_t k) -> int {
-            int cnt[WSEG];
-            uint32_t bar[WSEG];                                  // entries above bar[o] precede (k >= 1)
+        // -- the S best keys of all windows, in order: a tree of merges, one wave per pair of sorted runs ----------
+        // max(A[i], B[S-1-i]) holds the S largest keys of two descending runs A and B as a bitonic sequence, which
+        // eight compare-exchange stages sort; a lane holds four consecutive elements, so the two finest stages stay
+        // in its registers and the other six exchange with lanes 1 ... 32 away (DPP moves and shuffles): no barrier
+        // inside a merge, one between the levels of the tree.  (Ranking every window entry by binary searches in the
+        // other windows, as this kernel did before, took 5-6 us per strip: 50 dependent LDS reads per entry.)
+        const unsigned long long* top = s_wk;                 // one segment: its window is the order
+        {
+            unsigned long long* src = s_wk;
+            unsigned long long* dst = s_mk;
+            for (int runs = nseg; runs > 1; runs = (runs + 1) >> 1) {
+                const int pairs = (runs + 1) >> 1;
+                if (wave < pairs) {
+                    const unsigned long long* A = src + (2 * wave) * S;
+                    const bool has_b = 2 * wave + 1 < runs;
+                    const unsigned long long* B = src + (2 * wave + 1) * S;
+                    unsigned long long v[4];
+                    const int base = lane * 4;
 #pragma unroll
-            for (int o = 0; o < WSEG; ++o) { cnt[o] = 0; bar[o] = k - (o < l ? 1u : 0u); }
-            for (int st = S >> 1; st >= 1; st >>= 1) {
-                uint32_t v[WSEG];
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned long long x = A[base + e];
+                        const unsigned long long y = has_b ? B[S - 1 - base - e] : 0ull;
+                        v[e] = x > y ? x : y;
+                    }
+                    if (has_b) {
+                        bitonic_lane_stage<32, 4>(v, base, S);
+                        bitonic_lane_stage<16, 4>(v, base, S);
+                        bitonic_lane_stage<8, 4>(v, base, S);
+                        bitonic_lane_stage<4, 4>(v, base, S);
+                        bitonic_lane_stage<2, 4>(v, base, S);
+                        bitonic_lane_stage<1, 4>(v, base, S);
 #pragma unroll
-                for (int o = 0; o < WSEG; ++o) v[o] = s_win[o * S + cnt[o] + st - 1];
+                        for (int jj = 2; jj >= 1; jj >>= 1) {
 #pragma unroll
-                for (int o = 0; o < WSEG; ++o) cnt[o] += (v[o] > bar[o]) ? st : 0;
+                            for (int e = 0; e < 4; ++e) {
+                                if ((e & jj) == 0) {
+                                    const unsigned long long x = v[e], y = v[e | jj];
+                                    if (x < y) { v[e] = y; v[e | jj] = x; }
+                                }
+                            }
+                        }
+                    }
+                    unsigned long long* D = dst + wave * S;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) D[base + e] = v[e];
+                }
+                __syncthreads();
+                top = dst;
+                unsigned long long* t = src; src = dst; dst = t;
             }
-            int rank = i;
-#pragma unroll
-            for (int o = 0; o < WSEG; ++o) {                     // the search stops at S - 1: the last entry decides
-                cnt[o] += (cnt[o] == S - 1 && s_win[o * S + S - 1] > bar[o]) ? 1 : 0;
-                rank += (o < nseg && o != l) ? cnt[o] : 0;
-            }
-            return rank;
-        };
-        if (nseg > 1) {
-            if (tid < nseg * 16) {
-                const int l = tid >> 4, i = ((tid & 15) << 4) | 15;
-                const uint32_t key = s_win[l * S + i];
-                s_srank[tid] = key != 0u ? window_rank(l, i, key) : 0x7fffffff;
-            }
-            __syncthreads();
         }
 #ifdef OD_STAMPS_FINE
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
-        // thread = (window tid / 128, entry tid % 128); the upper halves of the windows take a second pass, which
-        // runs only if a window contributes more than 128 candidates
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int l = tid >> 7, i = (tid & 127) + u * 128;
-            const int e = l * S + i;
-            uint32_t key = (l < nseg && i < ns) ? s_win[e] : 0u;
-            if (nseg > 1 && key != 0u && i >= 16 && s_srank[(l << 4) + (i >> 4) - 1] >= ns) key = 0u;
-            if (__ballot(key != 0u) == 0ull) continue;
-            const int rank = nseg > 1 ? window_rank(l, i, key) : i;
-            if (key != 0u && rank < ns) {
-                const int slot = s_wslot[e];
+        if (tid < S) {
+            const unsigned long long key = tid < ns ? top[tid] : 0ull;
+            const bool ok = (key >> 32) != 0ull;
+            const int e = ok ? (int)(0xFFFFFFFFu - (uint32_t)key) : 0;
+            if (ok) {
                 const int lab = s_wlab[e];
-                s_strip[rank] = slot;
-                s_sraw[rank] = lab;
-                if (group) s_ckey[rank] = ((uint32_t)(lab - label_base) << 8) | (uint32_t)rank;
-                atomicMax(&s_taken[l], i + 1);
+                s_strip[tid] = s_wslot[e];
+                s_sraw[tid] = lab;
+                if (group) s_ckey[tid] = ((uint32_t)(lab - label_base) << 8) | (uint32_t)tid;
+            }
+            // entries taken from every window: they are a prefix of it
+#pragma unroll
+            for (int l = 0; l < WSEG; ++l) {
+                const unsigned long long m = __ballot(ok && (e >> 8) == l);
+                if (lane == 0 && m != 0ull) atomicAdd(&s_taken[l], __popcll(m));
             }
         }
         __syncthreads();
@@ -377,9 +520,10 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
         if (tid < nseg) { s_head[tid] += s_taken[tid]; s_taken[tid] = 0; }
+        }   // (windows)
         // the boxes of the strip are requested now and stored after the next loop
         float4 my_box = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < ns) my_box = boxes[s_strip[tid]];
+        if (tid < ns) my_box = from_order ? s_obox[s0 + tid] : boxes[s_strip[tid]];
         // -- position of every candidate in (class, rank) order: number of smaller (class, rank) keys --------------
         if (group) {
             const int r = tid & (S - 1), quarter = tid >> 8;
@@ -398,7 +542,9 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
 #ifdef OD_STAMPS_FINE
         if (stamp_i < 30) STAMP(stamp_i++);
 #endif
-        prefetch_windows();                                  // for the next strip: the heads are final
+        // for the next strip: the heads are final (inside the ranked head of the order there is nothing to request;
+        // its last strip requests the first windows, from the heads the ranking counted)
+        if (!from_order || (s0 + SL >= ranked_n && ranked_n < n_valid)) prefetch_windows();
         if (tid < ns) s_cpos[group ? s_crank[tid] : tid] = tid;
         __syncthreads();
 #ifdef OD_STAMPS

@@ -143,3 +143,29 @@ def test_sharded_inference_tail_on_gpu_world2():
     ret = mgr.dict()
     mp.spawn(_gpu_worker, args=(world, port, ret), nprocs=world, join=True)
     assert dict(ret) == {0: True, 1: True}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling,per_rank", [("strong", 8), ("weak", 16)])
+def test_bench_two_rank_rehearsal(scaling, per_rank):
+    """`bench.py --gpus 2` on a one-GPU machine (OD_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo): the launcher, the
+    shard of the global batch (strong) or the per-rank batch (weak), the ring of exchanges and the one JSON line of
+    rank 0, which says how many ranks joined the collective and how the batch was split."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OD_BENCH_REHEARSAL="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--scaling", scaling, "--steps", "16",
+                          "--warmup", "2", "--cpu-sample", "0", "--lean"], env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    line = json.loads([l for l in run.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == scaling
+    assert line["collective_backend"] == "gloo" and line["images_per_rank_per_step"] == per_rank
+    assert line["config"]["global_batch"] == 2 * per_rank and line["steps"] == 16
+    assert line["value"] > 0 and abs(line["value"] - 2 * per_rank * 16 / (line["ms_per_step"] * 16e-3)) < 1e-6 * line["value"]
+    assert line["detections_per_step"] > 0
