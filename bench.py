@@ -69,8 +69,22 @@ def pmc_table():
         return {}
 
 
+# profile id of a launch (od_profile) -> name of the kernel that runs under it for this workload (the one-launch matching
+# path reports under the ids of the chain's assign and restore steps)
+PMC_KERNEL_NAMES = {"match_assign": ("match_fused_kernel", "match_assign_kernel"),
+                    "match_restore": ("match_restore_lds_kernel", "match_restore_kernel")}
+
+
+def pmc_entry(kernel: str, table=None):
+    kernels_ = (table if table is not None else pmc_table()).get("kernels", {})
+    for name in PMC_KERNEL_NAMES.get(kernel, (kernel + "_kernel",)):
+        if name in kernels_:
+            return kernels_[name]
+    return None
+
+
 def pmc_traffic(kernel: str, table=None):
-    entry = (table if table is not None else pmc_table()).get("kernels", {}).get(kernel + "_kernel")
+    entry = pmc_entry(kernel, table)
     return None if entry is None else entry.get("hbm_bytes_per_launch")
 
 
@@ -199,7 +213,7 @@ def launch_ranks(n: int) -> int:
 
 def pmc_valu(kernel: str, table=None):
     """VALU instructions per launch (SQ_INSTS_VALU summed over the waves) from the committed counter pass, or None."""
-    entry = (table if table is not None else pmc_table()).get("kernels", {}).get(kernel + "_kernel")
+    entry = pmc_entry(kernel, table)
     return None if entry is None else entry.get("valu_insts_per_launch")
 
 

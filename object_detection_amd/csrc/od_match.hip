@@ -158,6 +158,10 @@ struct WaveTile {
     float bx1, by1, bx2, by2;    // bounding box of the wave's anchors (wave-uniform)
 };
 
+__device__ __forceinline__ float uniform_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
 __device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __restrict__ A, const long long (&first)[R],
                                                long long n) {
     const int lane = threadIdx.x & 63;
@@ -172,8 +176,9 @@ __device__ __forceinline__ void load_wave_tile(WaveTile& t, const float4* __rest
         bx1 = fminf(bx1, a.x); by1 = fminf(by1, a.y);
         bx2 = fmaxf(bx2, a.z); by2 = fmaxf(by2, a.w);
     }
-    t.bx1 = wave_fmin_all(bx1); t.by1 = wave_fmin_all(by1);
-    t.bx2 = wave_fmax_all(bx2); t.by2 = wave_fmax_all(by2);
+    // wave-uniform: kept in scalar registers
+    t.bx1 = uniform_f(wave_fmin_all(bx1)); t.by1 = uniform_f(wave_fmin_all(by1));
+    t.bx2 = uniform_f(wave_fmax_all(bx2)); t.by2 = uniform_f(wave_fmax_all(by2));
 }
 
 // Visit, in ascending GT order, every GT of [g_begin, g_end) whose box can overlap the wave's bounding
@@ -361,9 +366,11 @@ __global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void ma
         for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, chunk_done, 1, first_gt_chunk(gt, m0, nullptr, 0, M));
     }
 
+    int lane_again = lane;                           // opaque: the load indices do not stay in registers until here
+    asm volatile("" : "+v"(lane_again));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long long idx = first[r] + lane;
+        const long long idx = first[r] + lane_again;
         if (idx < n) {
             out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
             if (want_restore) put_argmax(ws, (long long)b * n + idx, bidx[r]);
@@ -829,7 +836,10 @@ constexpr int FHEAD = 7;             // entries of a light tile that share the 6
 constexpr int FEXTRA = LCAP - FHEAD - 1;   // further entry slots of a light tile; capacity FHEAD + FEXTRA
 constexpr int FCAP = FHEAD + FEXTRA;
 
-__global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void match_fused_kernel(
+#ifndef OD_FUSED_WAVES
+#define OD_FUSED_WAVES 7
+#endif
+__global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(OD_FUSED_WAVES))) void match_fused_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int coop_tiles,
     TileLayout layout, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws, int want_restore,
     float high, float low, long long* __restrict__ matched) {
@@ -940,12 +950,13 @@ __global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void ma
         if (want_restore && lane == 0) ws.tile_head[wslot * 8] = make_uint2(0u, 0u);
         return;
     }
-    constexpr int RESIDENT = 128;
+    // The first two GT chunks are requested together with the anchors: one memory round trip for the whole tile at up to
+    // 128 GT.  Longer lists go on in steps of 128 through the same code (one more round trip per step, not hidden by a
+    // prefetch: a second instance of the scoring code, or two more chunks in flight, would take the registers that
+    // keep seven waves per SIMD free of spills -- and spilled registers of 51 000 waves went to HBM, 43 MiB per launch).
     float4 gA = make_float4(0.f, 0.f, 0.f, 0.f), gB = gA;
-    if (M <= RESIDENT) {
-        if (lane < M) gA = gt[m0 + lane];
-        if (64 + lane < M) gB = gt[m0 + 64 + lane];
-    }
+    if (lane < M) gA = gt[m0 + lane];
+    if (64 + lane < M) gB = gt[m0 + 64 + lane];
     WaveTile t;
     load_wave_tile(t, A, first, n);
     float best[R];
@@ -963,19 +974,25 @@ __global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(7))) void ma
             ++lcount;
         }
     };
-    if (M <= RESIDENT) {
-        const unsigned long long maskA = __ballot(lane < M && overlaps_tile(t, gA));
-        const unsigned long long maskB = __ballot(64 + lane < M && overlaps_tile(t, gB));
-        int rank = 0;
-        visit_survivors(maskA, gA, 0, rank, 0, 1, eval);
-        if (maskB) visit_survivors(maskB, gB, 64, rank, 0, 1, eval);
-    } else {
-        for_each_overlapping_gt(t, gt, m0, nullptr, 0, M, 0, 1, eval, [&](int, uint32_t) {}, 1,
-                                first_gt_chunk(gt, m0, nullptr, 0, M));
+    int rank = 0;
+    for (int g0 = 0; g0 < M; g0 += 128) {
+        if (g0 > 0) {
+            gA = gB = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g0 + lane < M) gA = gt[m0 + g0 + lane];
+            if (g0 + 64 + lane < M) gB = gt[m0 + g0 + 64 + lane];
+        }
+        const unsigned long long maskA = __ballot(g0 + lane < M && overlaps_tile(t, gA));
+        const unsigned long long maskB = __ballot(g0 + 64 + lane < M && overlaps_tile(t, gB));
+        visit_survivors(maskA, gA, g0, rank, 0, 1, eval);
+        if (maskB) visit_survivors(maskB, gB, g0 + 64, rank, 0, 1, eval);
     }
+    // The lane number is made opaque here: otherwise the four 64-bit anchor indices formed for the tile's loads stay in
+    // vector registers until these stores (8 registers: the difference between seven waves per SIMD with and without spills).
+    int lane_again = lane;
+    asm volatile("" : "+v"(lane_again));
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-        const long long idx = first[r] + lane;
+        const long long idx = first[r] + lane_again;
         if (idx < n) {
             out[idx] = (best[r] < low) ? -1 : ((best[r] < high) ? -2 : (long long)bidx[r]);
             if (want_restore) put_argmax(ws, (long long)b * n + idx, bidx[r]);
@@ -1042,7 +1059,7 @@ __device__ __forceinline__ void tile_rows_from_lds(const float4* __restrict__ A,
 __global__ __launch_bounds__(RL_T) void match_restore_lds_kernel(
     const float4* __restrict__ anchors, long long anchor_batch_stride, long long n, int wtiles, int coop_tiles,
     TileLayout layout, const float4* __restrict__ gt, const int* __restrict__ gt_offsets, MatchWs ws,
-    long long* __restrict__ matched) {
+    long long* __restrict__ matched, int batch, int by_xcd) {
     extern __shared__ uint32_t s_max[];                  // [M] row maxima (ordered keys; 0 = nothing overlaps); only this workgroup's rows are kept
     __shared__ int s_hn, s_on, s_xn, s_cn;
     __shared__ int s_hs[HIT_CAP], s_hg[HIT_CAP];
@@ -1052,7 +1069,12 @@ __global__ __launch_bounds__(RL_T) void match_restore_lds_kernel(
     __shared__ int s_cw[CAND_CAP];                       // entries of this workgroup's rows: tile, GT, value key
     __shared__ uint32_t s_cg[CAND_CAP], s_ck[CAND_CAP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y, j = blockIdx.x, G = gridDim.x;
+    // grid (8 * G, ceil(batch / 8)): the G workgroups of an image share an XCD, hence its L2 -- the entry lines of the image
+    // are fetched into it once (workgroups go to the XCDs in turn by their linear number); grid (G, batch): plain
+    const int G = by_xcd ? (int)(gridDim.x >> 3) : (int)gridDim.x;
+    const int b = by_xcd ? (int)((blockIdx.x & 7u) + 8u * blockIdx.y) : (int)blockIdx.y;
+    const int j = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (b >= batch) return;
     const int m0 = gt_offsets[b];
     const int M = gt_offsets[b + 1] - m0;
     if (M <= 0) return;
@@ -1505,6 +1527,15 @@ static int restore_groups() {
     return v;
 }
 
+// OD_MATCH_XCD=0: plain grid of the fused path's restore kernel (default: its XCD-aware grid)
+static int xcd_mapping() {
+    static const int v = [] {
+        const char* e = getenv("OD_MATCH_XCD");
+        return e ? atoi(e) : 1;
+    }();
+    return v;
+}
+
 static size_t heavy_capacity(int64_t m_total, int32_t batch) {   // = entry_base(batch, m_total)
     return (size_t)HCAP_PER_GT * (size_t)(m_total > 0 ? m_total : 0) + 256 * (size_t)batch;
 }
@@ -1641,6 +1672,8 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
         if (m_total == 0) coop = 0;
         if (coop > (int)coop_cap(n)) coop = (int)coop_cap(n);
         if (coop > wtiles) coop = wtiles;
+        // (Dealing the blocks of tiles to the XCDs so that the shared anchor table crosses the fabric once instead of
+        // eight times cut the kernel's fetched bytes and made it 2 us slower: it is bound by vector instructions.)
         const long long light_blocks = ((long long)(wtiles - coop) + MT / 64 - 1) / (MT / 64);
         if (coop + light_blocks <= 65535) {
             OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_ASSIGN, match_fused_kernel, dim3((unsigned)batch, (unsigned)(coop + light_blocks)),
@@ -1648,9 +1681,12 @@ extern "C" int od_match_retinanet_grids(const float* anchors, int64_t anchor_bat
                              (const float4*)gt_boxes, gt_offsets, ws, restore, high, low, (long long*)matched);
             if (restore) {
                 const size_t lds = (size_t)(m_total > 0 ? m_total : 1) * sizeof(uint32_t);
-                OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_lds_kernel, dim3((unsigned)restore_groups(), (unsigned)batch),
+                const unsigned G = (unsigned)restore_groups();
+                const int r_xcd = xcd_mapping() ? 1 : 0;
+                const dim3 rgrid = r_xcd ? dim3(8u * G, (unsigned)((batch + 7) / 8)) : dim3(G, (unsigned)batch);
+                OD_LAUNCH_KERNEL(OD_KERNEL_MATCH_RESTORE, match_restore_lds_kernel, rgrid,
                                  dim3(RL_T), lds, s, (const float4*)anchors, stride, (long long)n, wtiles, coop, layout,
-                                 (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched);
+                                 (const float4*)gt_boxes, gt_offsets, ws, (long long*)matched, (int)batch, r_xcd);
             }
             return OD_OK;
         }

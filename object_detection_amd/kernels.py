@@ -162,15 +162,18 @@ def _pack_gt(gt_list: Sequence[Tensor], device: torch.device) -> Tuple[Tensor, T
         plain = plain and g.dtype is torch.float32 and g.dim() == 2
     m_total = offsets[-1]
     if m_total > 0:
-        first = gt_list[0]
         packed = None
+        k0 = next(i for i, g in enumerate(gt_list) if g.shape[0] > 0)
+        first = gt_list[k0]
         if plain and first.is_cuda:
-            # consecutive views of one buffer (pack_boxes): nothing to copy
-            p0 = first.data_ptr()
-            if all(g.data_ptr() == p0 + 16 * o and g.is_contiguous() and g.shape[-1] == 4
+            # consecutive views of one buffer (pack_boxes): nothing to copy.  Empty views carry no address of
+            # their own (data_ptr() is null), so only the views that hold boxes are placed.
+            p0 = first.data_ptr()            # the views before it are empty: its offset is 0
+            store = first.untyped_storage()
+            if all(g.shape[0] == 0 or (g.data_ptr() == p0 + 16 * o and g.is_contiguous() and g.shape[-1] == 4
+                                       and g.untyped_storage().data_ptr() == store.data_ptr())
                    for g, o in zip(gt_list, offsets)) and \
-                    first.untyped_storage().nbytes() - first.storage_offset() * 4 >= 16 * m_total and \
-                    all(g.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() for g in gt_list[1:]):
+                    store.nbytes() - first.storage_offset() * 4 >= 16 * m_total:
                 packed = torch.as_strided(first, (m_total, 4), (4, 1), first.storage_offset())
         if packed is not None:
             gt = packed

@@ -82,6 +82,30 @@ def test_match_retinanet_lists_that_overflow(device):
     check(small, [many, torch.cat([many] * 5)], "overflowed tiles")
 
 
+def test_packed_target_boxes_are_read_in_place(device):
+    """Views handed out by pack_boxes are recognised by the matching and loss launchers (no copy), images without
+    boxes at the head, in the middle and at the tail of the batch included; results equal those of separate tensors."""
+    gen = torch.Generator().manual_seed(5)
+    _, anchors = _anchors_cpu((256, 256), (32, 16), ((32,), (64,)), (0.5, 1.0, 2.0))
+    sizes = [0, 3, 0, 5, 1, 0]
+    separate = []
+    for m in sizes:
+        xy = torch.rand((m, 2), generator=gen) * 150
+        separate.append(torch.cat([xy, xy + 20 + torch.rand((m, 2), generator=gen) * 80], dim=1).to(device))
+    views = kernels.pack_boxes(separate)
+    assert [v.shape[0] for v in views] == sizes
+    gt, offsets, m_total = kernels._pack_gt(views, torch.device(device))
+    assert m_total == sum(sizes) and gt.data_ptr() == views[1].data_ptr() and gt.shape == (m_total, 4)
+    assert offsets.cpu().tolist() == [0, 0, 3, 3, 8, 9, 9]
+    # a list that is not one buffer in order is copied
+    swapped = [views[3], views[1]]
+    gt2, _, _ = kernels._pack_gt(swapped, torch.device(device))
+    assert gt2.data_ptr() not in (views[1].data_ptr(), views[3].data_ptr())
+    assert torch.equal(gt2, torch.cat(swapped))
+    a = anchors.to(device)
+    assert torch.equal(kernels.match_retinanet(a, views, 0.5, 0.4, True), kernels.match_retinanet(a, separate, 0.5, 0.4, True))
+
+
 def _grids_of(grids, per_location):
     """(first, row_len, rows) of every level of square pyramid grids with `per_location` anchors per cell."""
     out, first = [], 0

@@ -3,7 +3,7 @@ and value distributions (and, within stated floating-point tolerances, the fused
 restatement) -- matching (ragged pyramids, GT counts 0 ... 600, tiny and huge boxes, duplicates), candidate
 selection (level sizes 1 ... 300 000, 1 ... 91 classes, thresholds, K), batched NMS (both branches, both threshold
 rules, ties, duplicates) and the prediction tail.  Every failure prints the seed that reproduces it.
-Usage: python tools/fuzz_parity.py [seconds per section] [first seed]"""
+Usage: [FUZZ_SECTIONS=match,nms] python tools/fuzz_parity.py [seconds per section] [first seed]"""
 import math
 import os
 import sys
@@ -378,7 +378,10 @@ if __name__ == "__main__":
         assert run_seeds("tail", range(20)), "self-test: a perturbed checker went unnoticed"
         c_oracle.nms = real
         print("self-test ok: a perturbed checker is noticed")
+    only = [n for n in os.environ.get("FUZZ_SECTIONS", "").split(",") if n]      # e.g. FUZZ_SECTIONS=match,nms
     for name, _ in SECTIONS:
+        if only and name not in only:
+            continue
         t0, cases, seed, bad = time.time(), 0, SEED0, []
         while time.time() - t0 < BUDGET and len(bad) < 5:
             found = run_seeds(name, [seed])
