@@ -102,6 +102,37 @@ def clip_boxes_to_image(boxes: Tensor, size: Tuple[int, int]) -> Tensor:
     return clipped.reshape(boxes.shape)
 
 
+# Order among EQUAL scores, where torch leaves it open (``Tensor.topk``, the non-stable ``sort`` calls of nms and
+# _batched_nms_vanilla).  "ascending" (index) is the adopted rule, which the HIP kernels implement.  "descending" exists
+# to measure how much of a result hangs on that choice: ``with tie_order("descending"): ...`` reruns the restatement
+# with every such tie broken the other way round.
+_TIE_ORDER = "ascending"
+
+
+class tie_order:
+    def __init__(self, order: str):
+        assert order in ("ascending", "descending")
+        self.order = order
+
+    def __enter__(self):
+        global _TIE_ORDER
+        self.previous, _TIE_ORDER = _TIE_ORDER, self.order
+        return self
+
+    def __exit__(self, *exc):
+        global _TIE_ORDER
+        _TIE_ORDER = self.previous
+        return False
+
+
+def _argsort_desc(scores: Tensor) -> Tensor:
+    """Indices by descending score; equal scores by ascending index (or descending, see tie_order)."""
+    if _TIE_ORDER == "ascending":
+        return torch.sort(scores, dim=0, descending=True, stable=True)[1]
+    n = scores.shape[0]
+    return (n - 1) - torch.sort(scores.flip(0), dim=0, descending=True, stable=True)[1]
+
+
 def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, float_rule: bool = False) -> Tensor:
     """torchvision/csrc/ops/cpu/nms_kernel.cpp:nms_kernel_impl, vectorised over the inner loop.
 
@@ -116,7 +147,7 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, float_rule: bool = 
     s = scores.detach().cpu().float()
     x1, y1, x2, y2 = (np.ascontiguousarray(b[:, i]) for i in range(4))
     areas = (x2 - x1) * (y2 - y1)
-    order = torch.sort(s, dim=0, descending=True, stable=True)[1].numpy()
+    order = _argsort_desc(s).numpy()
     n = b.shape[0]
     suppressed = np.zeros(n, dtype=bool)
     keep = []
@@ -161,7 +192,7 @@ def _batched_nms_vanilla(boxes, scores, idxs, iou_threshold, float_rule: bool = 
         keep_mask[curr_indices[curr_keep]] = True
     keep_indices = torch.where(keep_mask)[0]
     # torchvision calls a non-stable sort here; adopted tie rule: ascending index.
-    return keep_indices[torch.sort(scores[keep_indices], descending=True, stable=True)[1]]
+    return keep_indices[_argsort_desc(scores[keep_indices])]
 
 
 def batched_nms(boxes, scores, idxs, iou_threshold, device_rule: str = "cpu"):
@@ -289,8 +320,8 @@ def _topk_min(input: Tensor, orig_kval: int, axis: int) -> int:
 
 def topk_stable(scores: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     """``Tensor.topk(k)`` with the adopted tie rule (descending value, ascending index)."""
-    vals, idx = torch.sort(scores, descending=True, stable=True)
-    return vals[:k], idx[:k]
+    idx = _argsort_desc(scores)[:k]
+    return scores[idx], idx
 
 
 # --------------------------------------------------------------------------------------------
