@@ -555,7 +555,7 @@ def main():
         return 1e3 * (time.perf_counter() - t1) / n
 
     # ---- secondary figures (not `value`) ------------------------------------------------------------------------
-    ms_timed_kernel = ms_graph = ms_api = ms_api_deferred = ms_api_blocking = ms_post = ms_match = None
+    ms_timed_kernel = ms_graph = ms_api = ms_api_deferred = ms_api_blocking = ms_post = ms_match = ms_long = None
     if use_graph:
         _C.profile_select(dom_id)
         _C.profile_stride(8)
@@ -569,6 +569,9 @@ def main():
         # list of per-image dictionaries, which are cut to size when first looked at.  `api`: a consumer looks at
         # the tensors of every image eight steps after the call (by then the counts have arrived: no wait);
         # `api_deferred`: nobody looks inside the loop; `blocking`: the host looks right after every call.
+        # the same eager step over 200 steps: a region of K steps costs about (fill + drain of the overlapped streams) +
+        # K x the steady-state step, so a short region (the driver times 20 steps) reads higher per step than a long one
+        ms_long = timed_loop(lambda i: eager_step(i)[1], 200) if world == 1 else None
         n_api = min(args.steps, 100)
         # (only the detections are held back for the consumer: keeping the 100 MB matched-index tensor of every step
         # alive as well would make the matching half write to fresh memory each step, which is not what is measured)
@@ -733,6 +736,8 @@ def main():
             },
             "kernels": probe,
             "roofline_all": roofline_all,
+            "ms_per_step_over_200_steps": ms_long,
+            "value_over_200_steps": (cfg.batch / (ms_long * 1e-3)) if ms_long else None,
             "reference_loops": reference_loops,
         }
         if world == 1 and args.cpu_sample > 0:

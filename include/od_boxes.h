@@ -212,6 +212,8 @@ int od_batched_nms(const float* boxes, const float* scores, const int32_t* label
  *   of 8192 boxes), otherwise OD_ERR_LIMIT (-2).
  *   All calls on one GPU share the array: calls that can overlap in time on one GPU (two streams, two threads) race
  *   and must be serialised by the caller.
+ *   The first call on a device looks up the array's address on that device (hipGetSymbolAddress), which is not a stream
+ *   operation: make one call per device outside any stream capture before recording the entry point into a HIP graph.
  */
 #define OD_NMS_NOALLOC_SCRATCH_BYTES (8u << 20)
 int od_batched_nms_noalloc(const float* boxes, const float* scores, const int32_t* labels, const int32_t* seg_count,
