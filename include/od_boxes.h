@@ -99,6 +99,17 @@ int od_match_retinanet_grids(const float* anchors, int64_t anchor_batch_stride, 
                              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Tuning knob of od_match_retinanet[_grids] (process-wide, like the profile switches below; no counterpart in the
+ * reference): the number of workgroups per image that share the low-quality restore of the two-launch path.  Every such
+ * workgroup holds a whole compute unit.  Many of them make the kernel short when the GPU has nothing else to do
+ * (default 16: a training step, where the losses wait for the matching); few of them leave the compute units to the
+ * kernels of other streams when matching runs beside other work (3 measured best for 16 images next to the inference
+ * pipeline).  Results do not depend on it.  groups in [2, 64]; 0 restores the default.  Returns the previous setting
+ * (0 = default) or OD_ERR_ARG.
+ */
+int od_match_restore_groups(int32_t groups);
+
+/*
  * FCOS centre-sampling matcher.  Replaces the matching loop of torchvision FCOS.compute_loss
  * (reference trigger retinanet_model.py:55-60 + train.py:62).  n_first_level / n_last_level are
  * num_anchors_per_level[0] / [-1] (lower bound 0 on the first level, upper bound inf on the last).

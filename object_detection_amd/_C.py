@@ -74,6 +74,7 @@ SIGNATURES = {
     "od_box_loss_backward": (c_int32, [_P, c_int32, c_int64, _P, c_int64, c_int64, _P, _P, _P, c_int32, c_int32, c_float,
                                        _P, c_float, c_float, _P, _P, _P, _P]),
     "od_preprocess_images": (c_int32, [_P, _P, _P, _P, _P, c_int32, c_int32, _P, _P, _P, c_int32, c_int32, _P]),
+    "od_match_restore_groups": (c_int32, [c_int32]),
     "od_profile_select": (c_int32, [c_int32]),
     "od_profile_stride": (c_int32, [c_int32]),
     "od_profile_read": (c_int32, [c_int32, _P, _P]),
@@ -118,6 +119,15 @@ def check(code: int, what: str) -> None:
     if code < 0:
         raise OdBoxesError(f"{what}: {_ERRORS.get(code, 'error')} (code {code})")
     raise OdBoxesError(f"{what}: HIP runtime error {code}")
+
+
+def match_restore_groups(groups: int) -> int:
+    """Workgroups per image of the matching path's restore kernel (0: the default); returns the previous setting.
+    Few (3) when matching runs beside other GPU work, the default (16) when the GPU waits for it."""
+    prev = lib().od_match_restore_groups(int(groups))
+    if prev < 0:
+        check(prev, "od_match_restore_groups")
+    return prev
 
 
 def profile_select(kernel_id: int) -> None:

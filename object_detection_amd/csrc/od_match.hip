@@ -31,6 +31,7 @@
 #include "od_common.h"
 #include "../../include/od_boxes.h"
 
+#include <atomic>
 #include <stdlib.h>
 #include <type_traits>
 #include <string.h>
@@ -1518,13 +1519,24 @@ static bool legacy_chain() {
     static const bool v = [] { const char* e = getenv("OD_MATCH_LEGACY"); return e && e[0] == '1'; }();
     return v;
 }
+// Workgroups per image of the fused path's restore kernel: od_match_restore_groups() if set, else the environment's
+// OD_MATCH_RESTORE_GROUPS, else 16 (shortest kernel with the GPU to itself).  Below 2 one workgroup would own every GT
+// row and list every entry of its image: more than its lists hold at ordinary sizes.
+static std::atomic<int> g_restore_groups{0};
 static int restore_groups() {
+    const int set = g_restore_groups.load(std::memory_order_relaxed);
+    if (set >= 2) return set;
     static const int v = [] {
         const char* e = getenv("OD_MATCH_RESTORE_GROUPS");
         const int g = e ? atoi(e) : 0;
-        return (g >= 1 && g <= 64) ? g : 8;
+        return (g >= 2 && g <= 64) ? g : 16;
     }();
     return v;
+}
+
+extern "C" int od_match_restore_groups(int32_t groups) {
+    if (groups != 0 && (groups < 2 || groups > 64)) return OD_ERR_ARG;
+    return g_restore_groups.exchange(groups, std::memory_order_relaxed);
 }
 
 // OD_MATCH_XCD=0: plain grid of the fused path's restore kernel (default: its XCD-aware grid)

@@ -82,6 +82,32 @@ def test_match_retinanet_lists_that_overflow(device):
     check(small, [many, torch.cat([many] * 5)], "overflowed tiles")
 
 
+def test_match_retinanet_restore_groups_knob(device):
+    """od_match_restore_groups only changes how the restore work is dealt out: every setting gives the checker's
+    answer (power-of-two and other counts, the bounds, 0 = default); values outside [2, 64] are refused."""
+    gen = torch.Generator().manual_seed(11)
+    _, anchors = _anchors_cpu((512, 512), (128, 64, 32, 16), ((16,), (32,), (64,), (128,)), (0.5, 1.0, 2.0))
+    gts = []
+    for m in (37, 0, 150):
+        xy = (torch.rand((m, 2), generator=gen) * 400).round()
+        gts.append(torch.cat([xy, xy + (10 + torch.rand((m, 2), generator=gen) * 120).round()], dim=1))
+    want = [c_oracle.match_retinanet(g.numpy(), anchors.numpy(), 0.5, 0.4, True) for g in gts]
+    a = anchors.to(device)
+    g_dev = [g.to(device) for g in gts]
+    assert _C.match_restore_groups(0) == 0
+    try:
+        for groups in (2, 3, 5, 8, 16, 64, 0):
+            _C.match_restore_groups(groups)
+            out = kernels.match_retinanet(a, g_dev, 0.5, 0.4, True).cpu()
+            for b in range(3):
+                assert np.array_equal(out[b].numpy(), want[b]), (groups, b)
+        for bad in (1, 65, -3):
+            with pytest.raises(_C.OdBoxesError):
+                _C.match_restore_groups(bad)
+    finally:
+        _C.match_restore_groups(0)
+
+
 def test_packed_target_boxes_are_read_in_place(device):
     """Views handed out by pack_boxes are recognised by the matching and loss launchers (no copy), images without
     boxes at the head, in the middle and at the tail of the batch included; results equal those of separate tensors."""
