@@ -105,8 +105,8 @@ def algorithmic_bytes(cfg, kernel: str, n_cand_per_image: float) -> float:
         "filter": 4.0 * B * N * C,                       # every logit read once
         "select": 12.0 * B * L * K + 48.0 * B * L * K,   # candidate keys + (reg, anchor, box out)
         "match_assign": B * (16.0 * N + 16.0 * M + 8.0 * N),   # anchors + GT read, int64 matched index written
-        "match_heavy": 0.0,                              # tiles of match_assign done cooperatively: its bytes are counted there
-        "match_init": 4.0 * B * M,                      # start value of every GT row maximum
+        "match_heavy": 0.0,                              # (four-launch chain only) tiles of match_assign done cooperatively: counted there
+        "match_init": 4.0 * B * M,                      # (four-launch chain only) start value of every GT row maximum
         "match_restore": 0.0,                            # patches a few anchors; no mandatory traffic
         "sample": 0.0,                                   # reads a 1/64 sample of the large levels; no mandatory traffic
         "filter_redo": 0.0,                              # repeats a level only when its sampled bound was too high
@@ -636,8 +636,8 @@ def main():
         stale = table.get("source_hashes") != source_hashes()
         traffic = pmc_traffic(dominant, table)
         valu = pmc_valu(dominant, table)
-        # every kernel of the step: contract bytes (SURVEY formulas), minimal bytes (a table shared by the batch counts
-        # once), counter traffic, duration alone and inside the overlapped step, and the fraction of the HBM peak each
+        # every kernel of the step: contract bytes (every input read once and every output written once, per image),
+        # minimal bytes (a table shared by the batch counts once), counter traffic, duration alone and inside the overlapped step, and the fraction of the HBM peak each
         # pair gives
         roofline_all = []
         for name, pr in sorted(probe.items(), key=lambda kv: -kv[1]["ms_per_launch"]):
