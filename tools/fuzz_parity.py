@@ -65,12 +65,17 @@ def fuzz_match(seed):
     lo = [0.3, 0.4, 0.5][ri(0, 2)]
     lq = ri(0, 3) != 0
     use_hint = ri(0, 1) == 1
-    out = kernels.match_retinanet(anchors.to(dev), [g.to(dev) for g in gts], hi, lo, lq,
-                                  grids=hint if use_hint else ()).cpu().numpy()
+    groups = (0, 2, 3, 8, 13)[ri(0, 4)]                  # workgroups per image of the restore kernel: never changes a result
+    _C.match_restore_groups(groups)
+    try:
+        out = kernels.match_retinanet(anchors.to(dev), [g.to(dev) for g in gts], hi, lo, lq,
+                                      grids=hint if use_hint else ()).cpu().numpy()
+    finally:
+        _C.match_restore_groups(0)
     for b, g in enumerate(gts):
         ref = c_oracle.match_retinanet(g.numpy(), anchors.numpy(), hi, lo, lq) if g.shape[0] else np.full(anchors.shape[0], -1)
         if not np.array_equal(out[b], ref):
-            return f"image {b}: {int((out[b] != ref).sum())} of {ref.size} differ (M={g.shape[0]}, N={anchors.shape[0]}, hint={use_hint}, lq={lq})"
+            return f"image {b}: {int((out[b] != ref).sum())} of {ref.size} differ (M={g.shape[0]}, N={anchors.shape[0]}, hint={use_hint}, lq={lq}, groups={groups})"
     return None
 
 
