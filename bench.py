@@ -637,8 +637,8 @@ def main():
         traffic = pmc_traffic(dominant, table)
         valu = pmc_valu(dominant, table)
         # every kernel of the step: contract bytes (every input read once and every output written once, per image),
-        # minimal bytes (a table shared by the batch counts once), counter traffic, duration alone and inside the overlapped step, and the fraction of the HBM peak each
-        # pair gives
+        # minimal bytes (a table shared by the batch counts once), counter traffic, duration alone and inside the
+        # overlapped step, and the fraction of the HBM peak each pair gives
         roofline_all = []
         for name, pr in sorted(probe.items(), key=lambda kv: -kv[1]["ms_per_launch"]):
             alone = pr["ms_per_launch"] * 1e-3
@@ -654,6 +654,13 @@ def main():
                 "frac_traffic_alone": frac(tr, alone), "valu_insts": pmc_valu(name, table),
             })
         longest = max(probe, key=lambda name: probe[name]["ms_per_launch"])
+        # the whole step against the HBM roofline: contract bytes of all its kernels / time per step; and the matching
+        # path as a whole (its contract bytes are moved by all matching kernels together, two launches or four)
+        step_bytes = sum(algorithmic_bytes(cfg, name, n_cand) * pr["launches_per_step"] for name, pr in probe.items())
+        step_s = elapsed / args.steps
+        match_alone_s = sum(pr["ms_per_launch"] * pr["launches_per_step"] for name, pr in probe.items()
+                            if name.startswith("match")) * 1e-3
+        match_bytes = algorithmic_bytes(cfg, "match_assign", n_cand)
         # a wave64 fp32 instruction occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz
         valu_issue_s = (valu * 4.0 / (NUM_CUS * 4 * 2.4e9)) if valu else None
         result = {
@@ -742,6 +749,14 @@ def main():
                 # the same kernel with the GPU to itself (single-stream probe)
                 "launch_us_alone": alone_s * 1e6,
                 "frac_alone": (abytes / alone_s / 1e9) / HBM_PEAK_GBS,
+                # `launch_us` is the time between the dispatch's start and end stamps while two other streams keep the
+                # chip busy: it includes the time the kernel's workgroups wait for compute units that other kernels
+                # hold, so it grows with the overlap, not with the kernel's own work (`launch_us_alone`, which is what
+                # the kernel statistics under profiles/ show: the tracer slows the host until the streams barely overlap)
+                "step_contract_MB": step_bytes / 1e6,
+                "step_frac": (step_bytes / step_s / 1e9 / HBM_PEAK_GBS) if step_s > 0 else None,
+                "matching_path_us_alone": match_alone_s * 1e6,
+                "matching_path_frac_alone": (match_bytes / match_alone_s / 1e9 / HBM_PEAK_GBS) if match_alone_s > 0 else None,
             },
             "kernels": probe,
             "roofline_all": roofline_all,
