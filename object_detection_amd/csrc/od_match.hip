@@ -1083,13 +1083,15 @@ __global__ __launch_bounds__(RL_T) void match_restore_lds_kernel(
     const long long image0 = (long long)b * n;
     const long long slot0 = (long long)b * wtiles;
     const int light_tiles = wtiles - coop_tiles;
-    // is GT `g` (index into the batch's list, as the entries hold it) one of this workgroup's rows?  G is a power of two
-    // in practice; the test is one subtraction and one AND then
+    // is GT `g` (index into the batch's list, as the entries hold it) one of this workgroup's rows?  With a power of
+    // two one subtraction and one AND; otherwise the quotient through a multiplication by ceil(2^32 / G), which is exact
+    // for row numbers below 2^32 / G (they are below 2^23) -- a division per entry was a quarter of the kernel at G = 3
     const uint32_t gmask = (uint32_t)G - 1u;
     const bool pow2 = (G & (G - 1)) == 0;
+    const uint32_t gmagic = (uint32_t)((0x100000000ull + (unsigned long long)G - 1ull) / (unsigned long long)G);
     auto mine = [&](uint32_t g) {
         const uint32_t l = g - (uint32_t)m0;
-        return pow2 ? (l & gmask) == (uint32_t)j : (l % (uint32_t)G) == (uint32_t)j;
+        return pow2 ? (l & gmask) == (uint32_t)j : (l - __umulhi(l, gmagic) * (uint32_t)G) == (uint32_t)j;
     };
 #ifdef OD_RL_STAMPS
     unsigned long long rst[8];
