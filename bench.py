@@ -267,12 +267,37 @@ def main():
         faulthandler.dump_traceback_later(170, exit=True)      # a hang ends with the stack of every thread
         local_rank = 0
     import torch.distributed as dist
-    if world > 1:
+    # OD_BENCH_DIST_SINGLE=1: a single rank goes through the multi-rank code as well (process group over RCCL, ranks_seen,
+    # the ring of all-gathers) -- the way to execute the RCCL calls of an N > 1 run on a machine with one GPU
+    dist_on = world > 1 or bool(os.environ.get("OD_BENCH_DIST_SINGLE"))
+    if dist_on:
         torch.cuda.set_device(local_rank)
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        # RCCL prints a version banner on stdout when its communicator is created (at the first collective); stdout
+        # carries the one JSON line and nothing else, so the banner goes to stderr
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                warm = torch.zeros((1,), dtype=torch.int32, device=torch.device("cuda", local_rank))
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     use_graph = args.graph
@@ -280,7 +305,7 @@ def main():
     global_cfg = synthetic.CFG2
     cfg, shard = global_cfg, None
     ranks_seen, backend = 1, None
-    if world > 1:
+    if dist_on:
         backend = dist.get_backend()
         ones = torch.ones((1,), dtype=torch.int32, device="cpu" if rehearsal else dev)
         dist.all_reduce(ones)                                   # every rank that joined adds one (over RCCL unless rehearsing)
@@ -370,7 +395,7 @@ def main():
         torch.cuda.set_stream(default_stream if single_stream or not two else s_posts[i % len(s_posts)])
         if mode == "padded":
             ob, os_, ol, oc = post_padded(r)
-            if world > 1:
+            if dist_on:
                 exchange(ob, os_, ol, oc)
             count_rows[i % len(count_rows)].copy_(oc, non_blocking=True)
             out = oc
@@ -418,7 +443,7 @@ def main():
         r = i % n_rot
         torch.cuda.set_stream(launch_streams[r & 1])
         ob, os_, ol, oc = graphs_post[r].replay()
-        if world > 1:
+        if dist_on:
             exchange(ob, os_, ol, oc)
         torch.cuda.set_stream(launch_streams[2])
         matched = graphs_match[r].replay()
@@ -427,11 +452,11 @@ def main():
     step = graph_step_run if use_graph else eager_step
 
     def sync():
-        if world > 1:
+        if dist_on:
             flush_exchanges()                              # detections still waiting in a ring travel now
         torch.cuda.set_stream(default_stream)
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
             torch.cuda.synchronize(dev)
@@ -460,7 +485,7 @@ def main():
                     or waited >= (2.0 if rehearsal else 20.0))
             if rehearsal:
                 print(f"[rank {rank}] spin-up batch {spin['batches']}: {1e3 * cur:.3f} ms/step", file=sys.stderr, flush=True)
-            if world > 1:                                 # the steps contain a collective: every rank runs the same number
+            if dist_on:                                 # the steps contain a collective: every rank runs the same number
                 import torch.distributed as dist
                 flag = torch.tensor([1 if stop else 0], dtype=torch.int32, device="cpu" if rehearsal else dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -577,7 +602,7 @@ def main():
         # `api_deferred`: nobody looks inside the loop; `blocking`: the host looks right after every call.
         # the same eager step over 200 steps: a region of K steps costs about (fill + drain of the overlapped streams) +
         # K x the steady-state step, so a short region (the driver times 20 steps) reads higher per step than a long one
-        ms_long = timed_loop(lambda i: eager_step(i)[1], 200) if world == 1 else None
+        ms_long = timed_loop(lambda i: eager_step(i)[1], 200) if not dist_on else None
         n_api = min(args.steps, 100)
         # (only the detections are held back for the consumer: keeping the 100 MB matched-index tensor of every step
         # alive as well would make the matching half write to fresh memory each step, which is not what is measured)
@@ -589,7 +614,7 @@ def main():
         torch.cuda.set_stream(default_stream)
         ms_post = timed_loop(lambda i: post_padded(i % n_rot), 20)
         ms_match = timed_loop(lambda i: model.match_anchors(batches[i % n_rot][1], anchors_per_image), 20)
-        if not use_graph and world == 1:
+        if not use_graph and not dist_on:
             # the recorded form of the step (two HIP graphs per resident batch, replayed on three launch streams)
             record_graphs()
             ms_graph = timed_loop(graph_step_run, min(args.steps, 100))
@@ -610,13 +635,13 @@ def main():
         _C.profile_select(_C.PROFILE_OFF)
         _C.profile_stride(1)
     reference_loops = None
-    if not args.lean and world == 1:
+    if not args.lean and not dist_on:
         torch.cuda.set_stream(default_stream)
         _C.match_restore_groups(0)                        # latency loops: the library's default
         reference_loops = reference_loop_figures(dev, timed_loop)
         _C.match_restore_groups(args.match_restore_groups)
 
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -714,7 +739,7 @@ def main():
                     (f", all-gather of the padded detections of {args.gather_every} steps at a time (" +
                      ("gloo over host memory: rehearsal on one GPU" if rehearsal else "RCCL") +
                      "): the collective runs once per " + str(args.gather_every) + " steps and stream, so ms_per_step "
-                     "holds an eighth of its cost, not a collective per step") if world > 1 else ""),
+                     "holds an eighth of its cost, not a collective per step") if dist_on else ""),
                 "resident_batches_in_rotation": n_rot,
                 "hip_streams_eager": args.streams,
                 "match_restore_groups": args.match_restore_groups,
@@ -764,11 +789,11 @@ def main():
             "value_over_200_steps": (cfg.batch / (ms_long * 1e-3)) if ms_long else None,
             "reference_loops": reference_loops,
         }
-        if world == 1 and args.cpu_sample > 0:
+        if not dist_on and args.cpu_sample > 0:
             result["cpu_baseline"] = cpu_baseline(cfg, args.cpu_sample)
         print(json.dumps(result))
 
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -83,12 +83,15 @@ def test_all_gather_detections_world2():
     assert dict(ret) == {0: True, 1: True}
 
 
-def _gpu_worker(rank, world, port, ret):
-    """Both ranks on GPU 0 (a one-GPU machine), exchange over gloo: the image-sharded inference tail -- NMS of the
-    rank's own images, od_pack_detections, one all-gather, unpack -- against the NMS of the whole batch."""
+def _gpu_worker(rank, world, port, ret, backend="gloo"):
+    """All ranks on GPU 0 (a one-GPU machine): the image-sharded inference tail -- NMS of the rank's own images,
+    od_pack_detections, one all-gather, unpack -- against the NMS of the whole batch.  Two ranks exchange over gloo;
+    a single rank can use the real backend ("nccl" = RCCL), which takes the device tensors as they are."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     from object_detection_amd import _C, kernels
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(11)                     # the same global batch on every rank
@@ -146,6 +149,22 @@ def test_sharded_inference_tail_on_gpu_world2():
 
 
 @pytest.mark.gpu
+def test_sharded_inference_tail_over_rccl_single_rank():
+    """The same exchange code through the backend a multi-GPU run uses (nccl = RCCL on ROCm), with the one rank a
+    one-GPU machine allows: the collective calls, dtypes, buffer reuse and the ring run through RCCL's own entry points
+    (a communicator of one rank copies its input to its output)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if not dist.is_nccl_available():
+        pytest.skip("this torch build has no nccl / RCCL backend")
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_gpu_worker, args=(1, port, ret, "nccl"), nprocs=1, join=True)
+    assert dict(ret) == {0: True}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("scaling,per_rank", [("strong", 8), ("weak", 16)])
 def test_bench_two_rank_rehearsal(scaling, per_rank):
     """`bench.py --gpus 2` on a one-GPU machine (OD_BENCH_REHEARSAL=1: both ranks on GPU 0, gloo): the launcher, the
@@ -169,3 +188,29 @@ def test_bench_two_rank_rehearsal(scaling, per_rank):
     assert line["config"]["global_batch"] == 2 * per_rank and line["steps"] == 16
     assert line["value"] > 0 and abs(line["value"] - 2 * per_rank * 16 / (line["ms_per_step"] * 16e-3)) < 1e-6 * line["value"]
     assert line["detections_per_step"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_through_rccl():
+    """`OD_BENCH_DIST_SINGLE=1 python bench.py`: one rank takes the multi-rank code path over the real backend (process
+    group, the all-reduce that counts the ranks, the ring of all-gathers over RCCL).  stdout carries the one JSON line
+    and nothing else -- RCCL's version banner included."""
+    import json
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if not dist.is_nccl_available():
+        pytest.skip("this torch build has no nccl / RCCL backend")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, OD_BENCH_DIST_SINGLE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OD_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "16", "--warmup", "2", "--cpu-sample", "0",
+                          "--lean"], env=env, capture_output=True, text=True, timeout=280)
+    assert run.returncode == 0, run.stderr[-2000:]
+    lines = [l for l in run.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), run.stdout[:500]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["collective_backend"] == "nccl"
+    assert "RCCL" in line["config"]["parallelism"] and line["value"] > 0 and line["detections_per_step"] > 0
