@@ -45,6 +45,13 @@ extern "C" {
  * threshold (the default here); csrc/ops/cuda/nms_kernel.cu compares the fp32 IoU with the threshold rounded to
  * float (this flag).  The reference runs on "cuda" when available (train.py:24, predict.py:25). */
 #define OD_NMS_THRESHOLD_FLOAT 0x100
+/* Or-ed into the mode: take the chip-wide bit-matrix form of the NMS (the shape of csrc/ops/cuda/nms_kernel.cu: an
+ * n x ceil(n/64) matrix of suppression words computed by all compute units, then one ordered pass) when the call
+ * qualifies -- num_seg*seg_stride <= OD_NMS_MATRIX_MAX_BOXES and a workspace of od_batched_nms_matrix_workspace_bytes.
+ * Otherwise the flag is ignored.  Same results; faster when thousands of boxes are KEPT (a plain nms over a few thousand
+ * boxes), slower for the pipeline's call, which keeps a few hundred and stops early. */
+#define OD_NMS_PREFER_MATRIX 0x200
+#define OD_NMS_MATRIX_MAX_BOXES 8192
 
 /* Library version (major*10000 + minor*100 + patch). */
 int od_version(void);
@@ -207,6 +214,8 @@ int od_select_candidates_planar(const float* const* cls_logits, const int64_t* c
  *   Up to 8 sorted segments are merged lazily, strip by strip; unsorted input is ranked first (O(n^2) comparisons).
  */
 size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride);
+/* workspace that lets OD_NMS_PREFER_MATRIX take effect (0: the call does not qualify); includes the size above */
+size_t od_batched_nms_matrix_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride);
 int od_batched_nms(const float* boxes, const float* scores, const int32_t* labels, const int32_t* seg_count,
                    int32_t num_seg, int32_t seg_stride, int32_t segments_sorted, int32_t batch,
                    double iou_threshold, int32_t mode, int32_t max_keep, int64_t* keep_idx, float* out_boxes,

@@ -22,6 +22,8 @@ OD_NMS_NOALLOC_SCRATCH_BYTES = 8 << 20
 OD_MAX_PREDICT_TAIL = 1024
 CODER_BOXCODER, CODER_LINEAR = 0, 1
 NMS_TRICK, NMS_VANILLA, NMS_AUTO_CPU, NMS_AUTO_GPU = 0, 1, 2, 3
+NMS_PREFER_MATRIX = 0x200       # or-ed into the mode: the chip-wide bit-matrix form when the call qualifies (see od_boxes.h)
+NMS_MATRIX_MAX_BOXES = 8192
 NMS_THRESHOLD_FLOAT = 0x100     # or-ed into the mode: compare the fp32 IoU with float(threshold), as torchvision's CUDA kernel
 
 _ERRORS = {
@@ -51,6 +53,7 @@ SIGNATURES = {
     "od_select_candidates_planar": (c_int32, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int32, c_int32, c_int32, _P,
                                               c_float, c_int32, c_int32, c_float, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "od_batched_nms_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "od_batched_nms_matrix_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "od_batched_nms": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,
                                  _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "od_batched_nms_noalloc": (c_int32, [_P, _P, _P, _P, c_int32, c_int32, c_int32, c_int32, c_double, c_int32, c_int32,

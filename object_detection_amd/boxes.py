@@ -46,6 +46,13 @@ def _threshold_flag(threshold_rule: str) -> int:
     return _C.NMS_THRESHOLD_FLOAT if threshold_rule == "cuda" else 0
 
 
+def _matrix_flag(n: int) -> int:
+    """These calls keep every survivor, which is what the strip kernel is slow at (it tests every strip against the
+    whole kept list); the chip-wide bit-matrix form is faster from a few hundred boxes on (600 boxes: 87 -> 38 us,
+    4145: 2.2 ms -> 0.15 ms) and takes up to 8192 boxes."""
+    return _C.NMS_PREFER_MATRIX if 256 < n <= _C.NMS_MATRIX_MAX_BOXES else 0
+
+
 def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, threshold_rule: str = "cuda") -> Tensor:
     """Indices kept by greedy NMS, sorted by decreasing score (stable), int64."""
     n = boxes.shape[0]
@@ -54,7 +61,7 @@ def nms(boxes: Tensor, scores: Tensor, iou_threshold: float, threshold_rule: str
     cnt = kernels._device_ints([n], boxes.device).reshape(1, 1)
     keep, _, _, _, count = kernels.batched_nms_padded(boxes.reshape(1, n, 4), scores.reshape(1, n), None, cnt, n,
                                                       False, float(iou_threshold),
-                                                      _C.NMS_TRICK | _threshold_flag(threshold_rule), n,
+                                                      _C.NMS_TRICK | _threshold_flag(threshold_rule) | _matrix_flag(n), n,
                                                       want_labels=False)
     return keep[0, : int(count.item())]
 
@@ -66,7 +73,7 @@ def batched_nms(boxes: Tensor, scores: Tensor, idxs: Tensor, iou_threshold: floa
     if n == 0:
         return torch.empty((0,), dtype=torch.int64, device=boxes.device)
     cnt = kernels._device_ints([n], boxes.device).reshape(1, 1)
-    mode = (_C.NMS_AUTO_GPU if mode is None else (mode & 0xff)) | _threshold_flag(threshold_rule)
+    mode = (_C.NMS_AUTO_GPU if mode is None else (mode & 0xff)) | _threshold_flag(threshold_rule) | _matrix_flag(n)
     keep, _, _, _, count = kernels.batched_nms_padded(boxes.reshape(1, n, 4), scores.reshape(1, n),
                                                       idxs.reshape(1, n), cnt, n, False, float(iou_threshold), mode,
                                                       n, want_labels=False)

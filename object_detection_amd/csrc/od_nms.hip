@@ -28,6 +28,7 @@
 #include "../../include/od_boxes.h"
 
 #include <mutex>
+#include <type_traits>
 
 namespace {
 
@@ -790,14 +791,19 @@ __global__ __launch_bounds__(NT) void nms_kernel(NmsArgs a) {
 
 // Global order of unsorted candidates (or of more than WSEG segments): rank of a candidate = number of valid
 // candidates with a greater key (score, then lower slot).  Keys are unique, so the ranks are a permutation:
-// order[rank] = slot.  O(n^2) comparisons spread over the whole chip: 256 candidates per workgroup against all
-// candidates, staged through LDS in tiles of 1024.
+// order[rank] = slot.  O(n^2) comparisons spread over the whole chip: a workgroup ranks 32 candidates against all
+// candidates, staged through LDS in tiles of 1024; eight threads share a candidate, each counting in an eighth of every
+// tile (with one thread per candidate and 256 candidates per workgroup a few thousand candidates made 17 workgroups
+// of 4000 serial comparisons: 62 us at n = 4145, now 13).
 constexpr int OT = 256;
 constexpr int OTILE = 1024;
+constexpr int OCAND = 32;                 // candidates per workgroup
+constexpr int OPARTS = OT / OCAND;        // threads per candidate
 __global__ __launch_bounds__(OT) void nms_order_kernel(const float* __restrict__ scores_all, const int* __restrict__ seg_count,
                                                        int num_seg, int seg_stride, int n_slots, int* __restrict__ order_all) {
     __shared__ unsigned long long s_key[OTILE];
     __shared__ int s_cnt[MAX_SEG];
+    __shared__ int s_part[OPARTS][OCAND];
     const int b = blockIdx.y;
     const float* scores = scores_all + (long long)b * n_slots;
     int* order = order_all + (long long)b * n_slots;
@@ -811,18 +817,304 @@ __global__ __launch_bounds__(OT) void nms_order_kernel(const float* __restrict__
         const int seg = i / seg_stride;
         return (i - seg * seg_stride < s_cnt[seg]) ? nms_key(scores[i], i) : 0ull;
     };
-    const int me = blockIdx.x * OT + threadIdx.x;
+    const int cand = threadIdx.x & (OCAND - 1), part = threadIdx.x / OCAND;
+    const int me = blockIdx.x * OCAND + cand;
     const unsigned long long mine = key_of(me);
     int rank = 0;
     for (int t0 = 0; t0 < n_slots; t0 += OTILE) {
         __syncthreads();
-        for (int i = threadIdx.x; i < OTILE; i += OT) s_key[i] = key_of(t0 + i);
+        for (int i = threadIdx.x; i < OTILE; i += OT) s_key[i] = key_of(t0 + i);     // past the end: 0, greater than no key
         __syncthreads();
-        const int lim = (n_slots - t0) < OTILE ? (n_slots - t0) : OTILE;
+        const unsigned long long* mykeys = s_key + part * (OTILE / OPARTS);
 #pragma unroll 8
-        for (int i = 0; i < lim; ++i) rank += (s_key[i] > mine) ? 1 : 0;
+        for (int i = 0; i < OTILE / OPARTS; ++i) rank += (mykeys[i] > mine) ? 1 : 0;
     }
-    if (mine != 0ull) order[rank] = me;
+    s_part[part][cand] = rank;
+    __syncthreads();
+    if (part == 0 && mine != 0ull) {
+#pragma unroll
+        for (int q = 1; q < OPARTS; ++q) rank += s_part[q][cand];
+        order[rank] = me;
+    }
+}
+
+// ---- NMS as a bit matrix over the whole chip ----------------------------------------------------------------
+// The form torchvision's CUDA kernel has (csrc/ops/cuda/nms_kernel.cu: an n x ceil(n / 64) matrix of "row i suppresses
+// column j" words, then one ordered pass over the rows), for the calls the strip kernel above is slow at: a plain nms
+// or batched_nms that KEEPS thousands of boxes (the strip kernel tests every strip against the whole kept list, beyond
+// 1024 kept boxes through memory: 1.8 ms to keep all of 4145).  Three launches after the global order:
+//   prepare  one workgroup per image: the mode decisions of nms_kernel (trick / vanilla, are the classes independent,
+//            the offset step), then boxes (offsets applied), areas and labels written in score order;
+//   matrix   one workgroup per 64 x 64 tile of the upper triangle, a wave per 16 rows, lane = column: the 64
+//            decisions of a row become one word through a ballot;
+//   scan     one workgroup per image walks the row blocks in order: a block's alive columns are what the kept rows of
+//            earlier blocks left, the greedy choice inside the block is a scalar loop over its set bits, and the words
+//            of the newly kept rows are or-ed into the later blocks' masks (the rows of the NEXT block are requested
+//            before the current one is resolved, whether they will be kept or not: one CU's latency, not its
+//            bandwidth, is what a dependent walk would wait for).  It stops at max_keep and writes the outputs.
+// Same decisions as nms_kernel (same intersection and division code), hence the same results bit for bit.
+constexpr int MX_MAXN = 8192;             // candidate slots per image this path takes (128 words per row)
+constexpr int MX_WMAX = MX_MAXN / 64;
+
+struct MatrixArgs {
+    NmsArgs a;
+    int4* header;               // [batch]: n_valid, compare labels?, -, -
+    float4* sbox;               // [batch, n_slots] boxes in score order (trick offsets applied)
+    float* sarea;               // [batch, n_slots]
+    int* slab;                  // [batch, n_slots] labels in score order (0 where labels are not compared)
+    unsigned long long* mask;   // [batch, n_slots, words]
+    unsigned long long* dcol;   // [batch, n_slots]: for column j, the rows of ITS OWN block of 64 that suppress it
+    int words;                  // ceil(n_slots / 64)
+};
+
+__global__ __launch_bounds__(NT) void nms_matrix_prepare_kernel(MatrixArgs m) {
+    __shared__ int s_segpre[MAX_SEG + 1];
+    __shared__ float s_ftmp[2 * (NT / 64)];
+    __shared__ int s_itmp[2 * (NT / 64)];
+    const NmsArgs& a = m.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const float4* boxes = a.boxes + (long long)b * a.n_slots;
+    const int* labels = a.labels ? a.labels + (long long)b * a.n_slots : nullptr;
+    const int* segc = a.seg_count + (long long)b * a.num_seg;
+    const int* order = a.order + (long long)b * a.n_slots;
+    if (tid == 0) {
+        int acc = 0;
+        for (int s = 0; s < a.num_seg; ++s) {
+            s_segpre[s] = acc;
+            int c = segc[s];
+            c = c < 0 ? 0 : (c > a.seg_stride ? a.seg_stride : c);
+            acc += c;
+        }
+        s_segpre[a.num_seg] = acc;
+    }
+    __syncthreads();
+    const int n_valid = s_segpre[a.num_seg];
+    // the decisions of nms_kernel, step by step the same
+    int mode = a.mode & NMS_MODE_MASK;
+    if (mode == OD_NMS_AUTO_CPU) mode = (4 * n_valid > 4000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
+    if (mode == OD_NMS_AUTO_GPU) mode = (4 * n_valid > 20000) ? OD_NMS_VANILLA : OD_NMS_TRICK;
+    const bool vanilla = (mode == OD_NMS_VANILLA) && labels != nullptr;
+    const bool trick = (mode == OD_NMS_TRICK) && labels != nullptr;
+    float step = 0.0f;
+    bool independent = vanilla;
+    bool one_class = labels == nullptr;
+    if (labels) {
+        float maxc = -__builtin_inff(), minc = __builtin_inff();
+        int maxl = (int)0x80000000, minl = 0x7fffffff;
+        for (int i = tid; i < a.n_slots; i += NT) {
+            const int seg = i / a.seg_stride;
+            const int r = i - seg * a.seg_stride;
+            if (r < s_segpre[seg + 1] - s_segpre[seg]) {
+                const float4 bx = boxes[i];
+                const int lab = labels[i];
+                maxc = fmaxf(maxc, fmaxf(fmaxf(bx.x, bx.y), fmaxf(bx.z, bx.w)));
+                minc = fminf(minc, fminf(fminf(bx.x, bx.y), fminf(bx.z, bx.w)));
+                maxl = lab > maxl ? lab : maxl;
+                minl = lab < minl ? lab : minl;
+            }
+        }
+        maxc = wave_fmax_all(maxc);
+        minc = wave_fmin_all(minc);
+        maxl = (int)(wave_umax_all((uint32_t)maxl ^ 0x80000000u) ^ 0x80000000u);
+        minl = (int)(~wave_umax_all(~((uint32_t)minl ^ 0x80000000u)) ^ 0x80000000u);
+        if (lane == 0) { s_ftmp[wave] = maxc; s_ftmp[NT / 64 + wave] = minc; s_itmp[wave] = maxl; s_itmp[NT / 64 + wave] = minl; }
+        __syncthreads();
+        maxc = s_ftmp[0]; minc = s_ftmp[NT / 64]; maxl = s_itmp[0]; minl = s_itmp[NT / 64];
+#pragma unroll
+        for (int w = 1; w < NT / 64; ++w) {
+            maxc = fmaxf(maxc, s_ftmp[w]);
+            minc = fminf(minc, s_ftmp[NT / 64 + w]);
+            maxl = s_itmp[w] > maxl ? s_itmp[w] : maxl;
+            minl = s_itmp[NT / 64 + w] < minl ? s_itmp[NT / 64 + w] : minl;
+        }
+        step = maxc + 1.0f;
+        if (trick) independent = a.can_skip_zero && minc >= 0.0f && minl >= 0 && ((float)maxl * step <= 8388608.0f);
+        one_class = (minl == maxl);
+    }
+    const bool by_class = independent && !one_class;
+    if (tid == 0) m.header[b] = make_int4(n_valid, by_class ? 1 : 0, 0, 0);
+    float4* sbox = m.sbox + (long long)b * a.n_slots;
+    float* sarea = m.sarea + (long long)b * a.n_slots;
+    int* slab = m.slab + (long long)b * a.n_slots;
+    for (int r = tid; r < n_valid; r += NT) {
+        const int slot = order[r];
+        float4 bx = boxes[slot];
+        const int raw = labels ? labels[slot] : 0;
+        if (trick) {
+            const float off = (float)raw * step;
+            bx.x += off; bx.y += off; bx.z += off; bx.w += off;
+        }
+        sbox[r] = bx;
+        sarea[r] = (bx.z - bx.x) * (bx.w - bx.y);
+        slab[r] = by_class ? raw : 0;
+    }
+}
+
+constexpr int MXT = 256;                  // threads of a matrix workgroup: four waves x 16 rows
+__global__ __launch_bounds__(MXT) void nms_matrix_kernel(MatrixArgs m) {
+    const int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
+    if (rb > cb) return;                                   // upper triangle only
+    const int4 h = m.header[b];
+    const int n_valid = h.x;
+    if (rb * 64 >= n_valid || cb * 64 >= n_valid) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* sbox = m.sbox + (long long)b * m.a.n_slots;
+    const float* sarea = m.sarea + (long long)b * m.a.n_slots;
+    const int* slab = m.slab + (long long)b * m.a.n_slots;
+    unsigned long long* mask = m.mask + (long long)b * m.a.n_slots * m.words;
+    const int j = cb * 64 + lane;
+    const bool jv = j < n_valid;
+    const int jq = jv ? j : n_valid - 1;
+    const float4 jb = sbox[jq];
+    const float jar = sarea[jq];
+    const int jlab = slab[jq];
+    const float thr_up = m.a.thr_up;
+    const int i0 = rb * 64 + wave * 16;
+#pragma unroll 4
+    for (int u = 0; u < 16; ++u) {
+        const int i = i0 + u;                              // wave-uniform
+        if (i >= n_valid) break;
+        const float4 ib = sbox[i];
+        const float inter = intersection(ib, jb);
+        const bool sup = jv && j > i && slab[i] == jlab && over_threshold_exact(inter, sarea[i], jar, thr_up);
+        const unsigned long long word = __ballot(sup);
+        if (lane == 0) mask[(long long)i * m.words + cb] = word;
+    }
+    if (rb == cb) {
+        // The diagonal tile once more, transposed: lane = row, a wave takes 16 columns, and a ballot gives the rows of
+        // the block that suppress a column -- the form in which the ordered pass resolves a block without a serial loop.
+        unsigned long long* dcol = m.dcol + (long long)b * m.a.n_slots;
+        const int c0 = cb * 64 + wave * 16;
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+            const int c = c0 + u;                          // wave-uniform column; this lane's row is j
+            if (c >= n_valid) break;
+            const float4 cbx = sbox[c];
+            const float inter = intersection(jb, cbx);
+            const bool sup = jv && c > j && slab[c] == jlab && over_threshold_exact(inter, jar, sarea[c], thr_up);
+            const unsigned long long word = __ballot(sup);
+            if (lane == 0) dcol[c] = word;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void nms_matrix_scan_kernel(MatrixArgs m) {
+    __shared__ unsigned long long s_removed[MX_WMAX];
+    __shared__ unsigned long long s_keptw;
+    __shared__ int s_segpre[MAX_SEG + 1];
+    __shared__ int s_nk;
+    const NmsArgs& a = m.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int n_valid = m.header[b].x;
+    const int W = m.words;
+    const unsigned long long* mask = m.mask + (long long)b * a.n_slots * W;
+    const unsigned long long* dcol = m.dcol + (long long)b * a.n_slots;
+    const int* order = a.order + (long long)b * a.n_slots;
+    int* kept_out = a.kept_out + (long long)b * a.n_slots;           // kept ranks in order
+    const int max_keep = a.max_keep < n_valid ? a.max_keep : n_valid;
+    if (tid < MX_WMAX) s_removed[tid] = 0ull;
+    if (tid == 0) {
+        s_nk = 0;
+        int acc = 0;
+        for (int s = 0; s < a.num_seg; ++s) {
+            s_segpre[s] = acc;
+            int c = a.seg_count[(long long)b * a.num_seg + s];
+            c = c < 0 ? 0 : (c > a.seg_stride ? a.seg_stride : c);
+            acc += c;
+        }
+        s_segpre[a.num_seg] = acc;
+    }
+    __syncthreads();
+    const int nblk = (n_valid + 63) >> 6;
+    // thread (g, w): word w of the rows 8 q + g of a block, q = 0 ... 7 (W <= 128 words, 1024 threads)
+    const int w = tid & (MX_WMAX - 1), g = tid >> 7;
+    // Four blocks are in flight: the words of block blk + 4 are requested when block blk is taken up (a block's turn is
+    // about a microsecond of scalar work and two barriers, a request a few microseconds of latency).
+    constexpr int DEPTH = 4;
+    unsigned long long nxt[DEPTH][8];
+    unsigned long long dnxt[DEPTH];                      // wave 0: lane l holds the rows of the block that suppress its column l
+    auto request = [&](auto slot_tag, int blk) {         // the words right of the diagonal of every row of the block
+        constexpr int SLOT = decltype(slot_tag)::value;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int row = blk * 64 + q * 8 + g;
+            // (no column block beyond nblk is ever written)
+            nxt[SLOT][q] = (blk < nblk && row < n_valid && w > blk && w < nblk) ? mask[(long long)row * W + w] : 0ull;
+        }
+        const int dc = blk * 64 + lane;
+        dnxt[SLOT] = (wave == 0 && blk < nblk && dc < n_valid) ? dcol[dc] : 0ull;
+    };
+    auto turn = [&](auto slot_tag, int blk) -> bool {    // returns true when max_keep is reached
+        constexpr int SLOT = decltype(slot_tag)::value;
+        unsigned long long cur[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) cur[q] = nxt[SLOT][q];
+        const unsigned long long diag = dnxt[SLOT];
+        request(slot_tag, blk + DEPTH);
+        if (wave == 0) {
+            // greedy choice inside the block = the fixed point of kept = alive & ~(some kept earlier row suppresses me),
+            // reached by ballot iteration from "every alive column is kept" (as in nms_kernel); then the cap
+            const bool alive = ((~s_removed[blk] >> lane) & 1ull) != 0ull && blk * 64 + lane < n_valid;
+            unsigned long long K = __ballot(alive);
+            for (int it = 0; it < 64; ++it) {
+                const unsigned long long K2 = __ballot(alive && ((diag & K) == 0ull));
+                if (K2 == K) break;
+                K = K2;
+            }
+            const int nk0 = s_nk;
+            const int room = max_keep - nk0;               // > 0: the walk stops when the cap is reached
+            const int before = __popcll(K & ((1ull << lane) - 1ull));
+            const bool kept_me = ((K >> lane) & 1ull) != 0ull && before < room;
+            const unsigned long long kept = __ballot(kept_me);
+            if (kept_me) kept_out[nk0 + before] = blk * 64 + lane;
+            if (lane == 0) { s_keptw = kept; s_nk = nk0 + __popcll(kept); }
+        }
+        __syncthreads();
+        const unsigned long long kept = s_keptw;
+        unsigned long long acc = 0ull;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc |= ((kept >> (q * 8 + g)) & 1ull) ? cur[q] : 0ull;
+        if (acc) atomicOr(&s_removed[w], acc);
+        const bool done = s_nk >= max_keep;
+        __syncthreads();
+        return done;
+    };
+    request(std::integral_constant<int, 0>{}, 0);
+    request(std::integral_constant<int, 1>{}, 1);
+    request(std::integral_constant<int, 2>{}, 2);
+    request(std::integral_constant<int, 3>{}, 3);
+    for (int blk = 0; blk < nblk; blk += DEPTH) {
+        if (turn(std::integral_constant<int, 0>{}, blk)) break;
+        if (blk + 1 >= nblk || turn(std::integral_constant<int, 1>{}, blk + 1)) break;
+        if (blk + 2 >= nblk || turn(std::integral_constant<int, 2>{}, blk + 2)) break;
+        if (blk + 3 >= nblk || turn(std::integral_constant<int, 3>{}, blk + 3)) break;
+    }
+    // outputs, as nms_kernel writes them
+    const int nk = s_nk;
+    const float4* boxes = a.boxes + (long long)b * a.n_slots;
+    const float* scores = a.scores + (long long)b * a.n_slots;
+    const int* labels = a.labels ? a.labels + (long long)b * a.n_slots : nullptr;
+    for (int k = tid; k < a.max_keep; k += NT) {
+        const long long o = (long long)b * a.max_keep + k;
+        if (k < nk) {
+            const int slot = order[kept_out[k]];
+            a.out_boxes[o] = boxes[slot];
+            a.out_scores[o] = scores[slot];
+            if (a.out_labels) a.out_labels[o] = labels ? (long long)labels[slot] : 0ll;
+            if (a.keep_idx) {
+                const int seg = slot / a.seg_stride;
+                a.keep_idx[o] = (long long)(s_segpre[seg] + (slot - seg * a.seg_stride));
+            }
+        } else {
+            a.out_boxes[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.out_scores[o] = 0.0f;
+            if (a.out_labels) a.out_labels[o] = 0ll;
+            if (a.keep_idx) a.keep_idx[o] = -1ll;
+        }
+    }
+    if (tid == 0) a.out_count[b] = nk;
 }
 
 // one thread per padded detection slot: six floats of the message row; thread 0 of an image appends the count
@@ -1113,6 +1405,29 @@ extern "C" size_t od_batched_nms_workspace_bytes(int32_t batch, int32_t num_seg,
     return 3 * part + nms_align256((size_t)batch * 256);
 }
 
+// Regions behind the strip kernel's workspace: header, boxes / areas / labels in score order, the bit matrix.
+struct MatrixLayout { size_t header, sbox, sarea, slab, dcol, mask, total; int words; };
+static MatrixLayout matrix_layout(int32_t batch, int32_t num_seg, int32_t seg_stride) {
+    MatrixLayout l{};
+    const size_t base = od_batched_nms_workspace_bytes(batch, num_seg, seg_stride);
+    const long long n = (long long)num_seg * seg_stride;
+    if (base == 0 || n > MX_MAXN) return l;
+    l.words = (int)((n + 63) / 64);
+    l.header = base;
+    l.sbox = l.header + nms_align256((size_t)batch * sizeof(int4));
+    l.sarea = l.sbox + nms_align256((size_t)batch * (size_t)n * sizeof(float4));
+    l.slab = l.sarea + nms_align256((size_t)batch * (size_t)n * sizeof(float));
+    l.dcol = l.slab + nms_align256((size_t)batch * (size_t)n * sizeof(int));
+    l.mask = l.dcol + nms_align256((size_t)batch * (size_t)n * sizeof(unsigned long long));
+    l.total = l.mask + nms_align256((size_t)batch * (size_t)n * (size_t)l.words * sizeof(unsigned long long));
+    return l;
+}
+
+extern "C" size_t od_batched_nms_matrix_workspace_bytes(int32_t batch, int32_t num_seg, int32_t seg_stride) {
+    if (batch < 0 || num_seg < 1 || seg_stride < 1) return 0;
+    return matrix_layout(batch, num_seg, seg_stride).total;
+}
+
 // Threshold rule folded into one float: a pair is suppressed when ovr >= the returned value.
 //   torchvision's CPU kernel (default):  (double)ovr > thr   <=>  ovr >= smallest float whose double value exceeds thr
 //   torchvision's CUDA kernel (OD_NMS_THRESHOLD_FLOAT):  ovr > (float)thr  <=>  ovr >= the float after (float)thr
@@ -1136,7 +1451,8 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
     if (num_seg > MAX_SEG || (long long)num_seg * seg_stride > MAXN || batch > 65535) return OD_ERR_LIMIT;
     const int rule = mode & ~NMS_MODE_MASK;
     const int base_mode = mode & NMS_MODE_MASK;
-    if (base_mode < OD_NMS_TRICK || base_mode > OD_NMS_AUTO_GPU || (rule & ~OD_NMS_THRESHOLD_FLOAT)) return OD_ERR_ARG;
+    if (base_mode < OD_NMS_TRICK || base_mode > OD_NMS_AUTO_GPU || (rule & ~(OD_NMS_THRESHOLD_FLOAT | OD_NMS_PREFER_MATRIX)))
+        return OD_ERR_ARG;
     if (((uintptr_t)boxes & 15) || ((uintptr_t)out_boxes & 15) || ((uintptr_t)workspace & 255)) return OD_ERR_ARG;
     if (workspace_bytes < od_batched_nms_workspace_bytes(batch, num_seg, seg_stride)) return OD_ERR_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
@@ -1149,7 +1465,7 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
     a.seg_stride = seg_stride;
     a.n_slots = num_seg * seg_stride;
     a.lazy = (segments_sorted && num_seg <= WSEG) ? 1 : 0;
-    a.thr_up = fold_threshold(iou_threshold, rule);
+    a.thr_up = fold_threshold(iou_threshold, rule & OD_NMS_THRESHOLD_FLOAT);
     a.can_skip_zero = (iou_threshold >= 0.0) ? 1 : 0;
     a.mode = base_mode;
     a.max_keep = max_keep;
@@ -1168,8 +1484,29 @@ static int batched_nms_launch(const float* boxes, const float* scores, const int
         OD_HIP(hipMemsetAsync(out_count, 0, sizeof(int) * (size_t)batch, s));
         return OD_OK;
     }
+    if (rule & OD_NMS_PREFER_MATRIX) {
+        const MatrixLayout l = matrix_layout(batch, num_seg, seg_stride);
+        if (l.total != 0 && workspace_bytes >= l.total) {
+            MatrixArgs m;
+            m.a = a;
+            m.header = (int4*)(w + l.header);
+            m.sbox = (float4*)(w + l.sbox);
+            m.sarea = (float*)(w + l.sarea);
+            m.slab = (int*)(w + l.slab);
+            m.mask = (unsigned long long*)(w + l.mask);
+            m.dcol = (unsigned long long*)(w + l.dcol);
+            m.words = l.words;
+            OD_LAUNCH_KERNEL(OD_KERNEL_NMS_ORDER, nms_order_kernel, dim3((unsigned)((a.n_slots + OCAND - 1) / OCAND), (unsigned)batch),
+                             dim3(OT), 0, s, scores, seg_count, (int)num_seg, (int)seg_stride, a.n_slots, a.order);
+            OD_LAUNCH_KERNEL(OD_KERNEL_NMS_ORDER, nms_matrix_prepare_kernel, dim3((unsigned)batch), dim3(NT), 0, s, m);
+            OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_matrix_kernel, dim3((unsigned)l.words, (unsigned)l.words, (unsigned)batch),
+                             dim3(MXT), 0, s, m);
+            OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_matrix_scan_kernel, dim3((unsigned)batch), dim3(NT), 0, s, m);
+            return OD_OK;
+        }
+    }
     if (!a.lazy) {
-        OD_LAUNCH_KERNEL(OD_KERNEL_NMS_ORDER, nms_order_kernel, dim3((unsigned)((a.n_slots + OT - 1) / OT), (unsigned)batch),
+        OD_LAUNCH_KERNEL(OD_KERNEL_NMS_ORDER, nms_order_kernel, dim3((unsigned)((a.n_slots + OCAND - 1) / OCAND), (unsigned)batch),
                          dim3(OT), 0, s, scores, seg_count, (int)num_seg, (int)seg_stride, a.n_slots, a.order);
     }
     OD_LAUNCH_KERNEL(OD_KERNEL_NMS, nms_kernel, dim3((unsigned)batch), dim3(NT), 0, s, a);

@@ -474,9 +474,13 @@ def batched_nms_padded(boxes: Tensor, scores: Tensor, labels: Optional[Tensor], 
     out_labels = torch.empty((B, max_keep), dtype=torch.int64, device=dev) if want_labels else None
     out_count = torch.empty((B,), dtype=torch.int32, device=dev)
     lib = _C.lib()
-    nbytes = _ws_bytes.get(("nms", B, num_seg, int(seg_stride)))
+    matrix = bool(int(mode) & _C.NMS_PREFER_MATRIX)
+    nbytes = _ws_bytes.get(("nms", B, num_seg, int(seg_stride), matrix))
     if nbytes is None:
-        nbytes = _ws_bytes[("nms", B, num_seg, int(seg_stride))] = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
+        nbytes = lib.od_batched_nms_workspace_bytes(B, num_seg, int(seg_stride))
+        if matrix:                                     # 0: the call does not qualify, the flag will be ignored
+            nbytes = max(nbytes, lib.od_batched_nms_matrix_workspace_bytes(B, num_seg, int(seg_stride)))
+        _ws_bytes[("nms", B, num_seg, int(seg_stride), matrix)] = nbytes
     if nbytes == 0 and B > 0:
         raise _C.OdBoxesError(f"od_batched_nms: {num_seg * seg_stride} boxes per image in {num_seg} segments exceed the "
                               f"limits of {_C.OD_MAX_NMS_BOXES} boxes and 64 segments")

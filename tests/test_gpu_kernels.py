@@ -456,6 +456,82 @@ def test_batched_nms_trick_when_classes_are_not_separated(device):
     assert len(ref_v) > 0 and len(ref_t) > 0
 
 
+@pytest.mark.parametrize("n,classes,extent", [(1, 1, 400), (65, 3, 100), (300, 1, 60), (1500, 5, 150), (4145, 4, 1024), (6000, 1, 800),
+                                              (8192, 7, 500)])
+def test_batched_nms_matrix_form(device, n, classes, extent):
+    """OD_NMS_PREFER_MATRIX: the chip-wide bit-matrix form gives the checker's keep list (both branches, both
+    threshold rules, score ties, caps), i.e. what the strip kernel gives; unsorted input in one segment."""
+    gen = torch.Generator().manual_seed(7 * n + classes)
+    boxes = _random_boxes(n, gen, float(extent))
+    scores = torch.rand(n, generator=gen)
+    scores[::7] = scores[0]
+    labels = torch.randint(0, classes, (n,), generator=gen)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    M = _C.NMS_PREFER_MATRIX
+    assert _C.lib().od_batched_nms_matrix_workspace_bytes(1, 1, n) > _C.lib().od_batched_nms_workspace_bytes(1, 1, n)
+    dev = (boxes[None].to(device), scores[None].to(device), labels[None].to(device))
+    for mode, omode in ((_C.NMS_TRICK, 0), (_C.NMS_VANILLA, 1)):
+        for flag, frule, thr in ((0, False, 0.3), (_C.NMS_THRESHOLD_FLOAT, True, 0.5)):
+            ref = c_oracle.batched_nms(boxes.numpy(), scores.numpy(), labels.numpy(), thr, omode, float_rule=frule)
+            for max_keep in (n, max(1, len(ref) // 3)):
+                keep, ob, os_, ol, oc = kernels.batched_nms_padded(*dev, cnt, n, False, thr, mode | flag | M, max_keep)
+                k = int(oc.item())
+                assert k == min(max_keep, len(ref)), (mode, thr, k, len(ref))
+                assert np.array_equal(keep[0, :k].cpu().numpy(), ref[:k]), (mode, thr)
+                assert torch.equal(ob[0, :k].cpu(), boxes[ref[:k]]) and torch.equal(os_[0, :k].cpu(), scores[ref[:k]])
+                assert torch.equal(ol[0, :k].cpu(), labels[ref[:k]])
+                assert float(ob[0, k:].abs().sum()) == 0.0 and bool((keep[0, k:] == -1).all())
+    # no labels (plain nms) through the public wrapper, which picks this form above 1024 boxes
+    from object_detection_amd import boxes as box_ops
+    ref = c_oracle.nms(boxes.numpy(), scores.numpy(), 0.4, True)
+    assert np.array_equal(box_ops.nms(boxes.to(device), scores.to(device), 0.4).cpu().numpy(), ref)
+
+
+def test_batched_nms_matrix_form_segments_and_mixed_classes(device):
+    """The matrix form on what the pipeline hands over (sorted padded segments, ragged counts, a batch) and on inputs
+    whose classes the coordinate trick does not separate (negative coordinates, negative threshold, negative labels,
+    offsets beyond 2^23); too many boxes for the form: the flag is ignored."""
+    gen = torch.Generator().manual_seed(4242)
+    B, num_seg, seg_stride, max_keep = 3, 6, 1000, 500
+    boxes, scores, labels, counts = _segmented_nms_case(gen, B, num_seg, seg_stride, 4, 1024)
+    dev = [t.to(device) for t in (boxes, scores, labels, counts)]
+    for mode, omode in ((_C.NMS_AUTO_GPU, 0), (_C.NMS_VANILLA, 1)):
+        keep, ob, os_, ol, oc = kernels.batched_nms_padded(dev[0], dev[1], dev[2], dev[3], seg_stride, True, 0.3,
+                                                           mode | _C.NMS_PREFER_MATRIX | _C.NMS_THRESHOLD_FLOAT, max_keep)
+        plain = kernels.batched_nms_padded(dev[0], dev[1], dev[2], dev[3], seg_stride, True, 0.3,
+                                           mode | _C.NMS_THRESHOLD_FLOAT, max_keep)
+        for b in range(B):
+            valid = (torch.arange(seg_stride)[None, :] < counts[b][:, None]).reshape(-1)
+            vb, vs, vl = boxes[b][valid], scores[b][valid], labels[b][valid]
+            ref = c_oracle.batched_nms(vb.numpy(), vs.numpy(), vl.numpy(), 0.3, omode, float_rule=True)[:max_keep]
+            k = int(oc[b].item())
+            assert k == len(ref) and np.array_equal(keep[b, :k].cpu().numpy(), ref), (mode, b)
+            assert torch.equal(ob[b, :k].cpu(), vb[ref]) and torch.equal(ol[b, :k].cpu(), vl[ref].long())
+        for got, want in zip((keep, ob, os_, ol, oc), plain):
+            assert torch.equal(got, want)
+    n = 700
+    bx0 = _random_boxes(n, gen, 300.0, 120.0) - 150.0
+    sc = torch.rand(n, generator=gen)
+    lab0 = torch.randint(0, 3, (n,), generator=gen)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    for bx, lab, thr in [(bx0, lab0, 0.3), (bx0 + 150.0, lab0, -0.5), (bx0 + 150.0, lab0 - 1, 0.3), (bx0 + 150.0, lab0 * 40000, 0.3)]:
+        ref = c_oracle.batched_nms(bx.numpy(), sc.numpy(), lab.numpy(), thr, 0)
+        keep, _, _, ol, oc = kernels.batched_nms_padded(bx[None].to(device), sc[None].to(device), lab[None].to(device), cnt, n,
+                                                        False, thr, _C.NMS_TRICK | _C.NMS_PREFER_MATRIX, n)
+        k = int(oc.item())
+        assert k == len(ref) and np.array_equal(keep[0, :k].cpu().numpy(), ref), thr
+        assert torch.equal(ol[0, :k].cpu(), lab[ref])
+    # 9000 boxes: beyond the form's limit, the strip kernel answers
+    assert _C.lib().od_batched_nms_matrix_workspace_bytes(1, 1, 9000) == 0
+    n = 9000
+    bx, sc2 = _random_boxes(n, gen, 500.0), torch.rand(n, generator=gen)
+    ref = c_oracle.nms(bx.numpy(), sc2.numpy(), 0.5, True)
+    cnt = torch.tensor([[n]], dtype=torch.int32, device=device)
+    keep, _, _, _, oc = kernels.batched_nms_padded(bx[None].to(device), sc2[None].to(device), None, cnt, n, False, 0.5,
+                                                   _C.NMS_TRICK | _C.NMS_THRESHOLD_FLOAT | _C.NMS_PREFER_MATRIX, n, want_labels=False)
+    assert np.array_equal(keep[0, :int(oc.item())].cpu().numpy(), ref)
+
+
 def test_nms_kat_and_degenerate(device):
     b = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.]])
     s = torch.tensor([.9, .8, .7])

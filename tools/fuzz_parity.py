@@ -141,13 +141,14 @@ def fuzz_nms(seed):
     float_rule = ri(0, 1) == 1
     keep_cap = [n, ri(1, n), 100][ri(0, 2)]
     cnt = torch.tensor([[n]], dtype=torch.int32, device=dev)
+    matrix = _C.NMS_PREFER_MATRIX if ri(0, 1) else 0      # the chip-wide bit-matrix form: the same results
     ref = c_oracle.batched_nms(boxes.numpy(), scores.numpy(), labels.numpy(), thr, omode, float_rule)[:keep_cap]
     keep, ob, os_, ol, oc = kernels.batched_nms_padded(boxes[None].to(dev), scores[None].to(dev), labels[None].to(dev), cnt,
-                                                       n, False, thr, mode | (_C.NMS_THRESHOLD_FLOAT if float_rule else 0),
+                                                       n, False, thr, mode | (_C.NMS_THRESHOLD_FLOAT if float_rule else 0) | matrix,
                                                        keep_cap)
     k = int(oc.item())
     if k != len(ref) or not np.array_equal(keep[0, :k].cpu().numpy(), ref):
-        return f"keep list differs: {k} vs {len(ref)} (n={n}, classes={classes}, thr={thr}, mode={omode}, float={float_rule}, cap={keep_cap})"
+        return f"keep list differs: {k} vs {len(ref)} (n={n}, classes={classes}, thr={thr}, mode={omode}, float={float_rule}, cap={keep_cap}, matrix={matrix})"
     if not torch.equal(ob[0, :k].cpu(), boxes[ref]) or not torch.equal(ol[0, :k].cpu(), labels[ref]):
         return "gathered outputs differ"
     return None
@@ -207,8 +208,9 @@ def fuzz_nms_segments(seed):
     mode, omode = [(_C.NMS_TRICK, 0), (_C.NMS_VANILLA, 1)][ri(0, 1)]
     float_rule = ri(0, 1) == 1
     max_keep = [1, ri(2, 100), 500, n][ri(0, 3)]
+    matrix = _C.NMS_PREFER_MATRIX if ri(0, 1) else 0
     keep, ob, os_, ol, oc = kernels.batched_nms_padded(boxes.to(dev), scores.to(dev), labels.to(dev), counts.to(dev), seg_stride,
-                                                       True, thr, mode | (_C.NMS_THRESHOLD_FLOAT if float_rule else 0), max_keep)
+                                                       True, thr, mode | (_C.NMS_THRESHOLD_FLOAT if float_rule else 0) | matrix, max_keep)
     for b in range(B):
         valid = (torch.arange(seg_stride)[None, :] < counts[b][:, None]).reshape(-1)
         vb, vs, vl = boxes[b][valid], scores[b][valid], labels[b][valid]
@@ -217,7 +219,7 @@ def fuzz_nms_segments(seed):
         k = int(oc[b].item())
         if k != len(ref) or not np.array_equal(keep[b, :k].cpu().numpy(), ref):
             return (f"image {b}: keep list differs ({k} vs {len(ref)}; segments {num_seg} x {seg_stride}, classes {classes}, "
-                    f"thr {thr}, mode {omode}, float {float_rule}, cap {max_keep})")
+                    f"thr {thr}, mode {omode}, float {float_rule}, cap {max_keep}, matrix {matrix})")
         if not torch.equal(ob[b, :k].cpu(), vb[ref]) or not torch.equal(os_[b, :k].cpu(), vs[ref]) \
                 or not torch.equal(ol[b, :k].cpu(), vl[ref].long()):
             return f"image {b}: gathered outputs differ"
