@@ -3,7 +3,7 @@ and value distributions (and, within stated floating-point tolerances, the fused
 restatement) -- matching (ragged pyramids, GT counts 0 ... 600, tiny and huge boxes, duplicates), candidate
 selection (level sizes 1 ... 300 000, 1 ... 91 classes, thresholds, K), batched NMS (both branches, both threshold
 rules, ties, duplicates) and the prediction tail.  Every failure prints the seed that reproduces it.
-Usage: [FUZZ_SECTIONS=match,nms] python tools/fuzz_parity.py [seconds per section] [first seed]"""
+Usage: [FUZZ_SECTIONS=match,nms] python tests/fuzz_parity.py [seconds per section] [first seed]"""
 import math
 import os
 import sys

@@ -840,12 +840,12 @@ def test_prediction_loop_tail_on_model_detections(device):
 @pytest.mark.parametrize("section,cases", [("match", 60), ("select", 60), ("nms", 150), ("nms_segments", 150),
                                            ("fcos", 100), ("tail", 300), ("focal", 25), ("boxloss", 150)])
 def test_random_shapes_against_the_scalar_checker(device, section, cases):
-    """A fixed run of the randomised parity tool (tools/fuzz_parity.py): ragged pyramids and GT lists, level sizes from
+    """A fixed run of the randomised parity tool (tests/fuzz_parity.py): ragged pyramids and GT lists, level sizes from
     1 to 300 000 logits with 1 ... 91 classes, NMS in both branches under both threshold rules, the prediction tail --
     every case bit for bit against oracle/od_oracle.c; the fused head losses against the torch restatement within the
     tolerances the tool states."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(GOLD), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(GOLD), "fuzz_parity.py"))
     fuzz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fuzz)
     bad = fuzz.run_seeds(section, range(1000, 1000 + cases))
