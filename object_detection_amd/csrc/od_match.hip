@@ -1003,7 +1003,10 @@ __global__ __launch_bounds__(MT) __attribute__((amdgpu_waves_per_eu(OD_FUSED_WAV
 }
 
 // Low-quality restore of the one-launch path.  See the section comment above.
-constexpr int RL_T = 1024;           // threads of a workgroup
+#ifndef OD_RL_T
+#define OD_RL_T 1024
+#endif
+constexpr int RL_T = OD_RL_T;        // threads of a workgroup
 constexpr int RL_W = RL_T / 64;
 constexpr int RL_WPT = 12;           // 16-byte words of the tiles' lines a thread requests together
 constexpr int HIT_CAP = 1024;        // hits a workgroup lists; beyond that it re-examines every tile for its rows
