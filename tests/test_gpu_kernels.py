@@ -532,6 +532,29 @@ def test_batched_nms_matrix_form_segments_and_mixed_classes(device):
     assert np.array_equal(keep[0, :int(oc.item())].cpu().numpy(), ref)
 
 
+def test_batched_nms_matrix_form_edge_cases(device):
+    """The matrix form on a batch with an image without candidates, without labels, with max_keep 1 and with a cap
+    that ends the walk inside a block."""
+    gen = torch.Generator().manual_seed(808)
+    B, n = 3, 700
+    boxes = torch.stack([_random_boxes(n, gen, 200.0) for _ in range(B)])
+    scores = torch.rand((B, n), generator=gen)
+    counts = torch.tensor([[n], [0], [333]], dtype=torch.int32)
+    dev = [t.to(device) for t in (boxes, scores, counts)]
+    flags = _C.NMS_TRICK | _C.NMS_THRESHOLD_FLOAT | _C.NMS_PREFER_MATRIX
+    for max_keep in (1, 70, n):
+        keep, ob, os_, _, oc = kernels.batched_nms_padded(dev[0], dev[1], None, dev[2], n, False, 0.4, flags, max_keep,
+                                                          want_labels=False)
+        for b in range(B):
+            m = int(counts[b, 0])
+            ref = c_oracle.nms(boxes[b, :m].numpy(), scores[b, :m].numpy(), 0.4, True)[:max_keep] if m else np.zeros(0, np.int64)
+            k = int(oc[b].item())
+            assert k == len(ref), (max_keep, b, k, len(ref))
+            assert np.array_equal(keep[b, :k].cpu().numpy(), ref), (max_keep, b)
+            assert torch.equal(ob[b, :k].cpu(), boxes[b][ref]) and torch.equal(os_[b, :k].cpu(), scores[b][ref])
+            assert bool((keep[b, k:] == -1).all()) and float(ob[b, k:].abs().sum()) == 0.0
+
+
 def test_nms_kat_and_degenerate(device):
     b = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.]])
     s = torch.tensor([.9, .8, .7])
